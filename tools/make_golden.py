@@ -1,0 +1,467 @@
+#!/usr/bin/env python3
+"""
+Golden-vector generator: runs the REFERENCE (kofinandi/pixel-nerf-yolo, read-only at
+/root/reference) on CPU on seeded inputs and writes small input/output fixtures to
+tests/golden/*.npz.  It runs ONLY in the build container; nothing under tests/, bench.py or
+smoke() imports the reference (it does not exist on the GPU box).
+
+The reference has no golden vectors or known-answer tests of its own, so the
+oracle (oracle/pnyolo_oracle.py) is pinned by what this script captures.
+
+Import shims: the reference imports five absent third-party modules at module
+top level -- cv2, torchvision(+.transforms, .models), dotmap, pyhocon, models.yolo (external
+NeRF-YOLO checkout).  They are replaced in sys.modules by inert stubs; none of their
+arithmetic is emulated:
+  * dotmap.DotMap     -> dict with attribute access + toDict() (container only)
+  * pyhocon           -> only needed for `import`; configs are the Conf class below, which
+                         implements the ConfigTree accessors the reference calls
+  * torchvision.models.resnet34 -> a local nn.Module with the public ResNet-34 layout
+                         (BasicBlock [3,4,6,3]) built from torch.nn conv/bn; torchvision itself
+                         stays absent, so results at that boundary are PARITY UNPINNED vs
+                         torchvision and pinned only vs torch's own conv2d/batch_norm.
+  * YOLOEncoder       -> not constructible here (needs ../NeRF-YOLO + yolov7.pt); the YOLO-mode
+                         fixture patches a dummy module with dims=[1792] and feeds the latent
+                         directly (encoder output is an input of the path; PARITY UNPINNED).
+Usage:  python tools/make_golden.py            (writes tests/golden/)
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_SRC = "/root/reference/src"
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+import pnyolo_pkg  # noqa: E402
+
+pnyolo_pkg.load()
+from pixel_nerf_yolo_amd import synth  # noqa: E402
+
+
+# --------------------------------------------------------------------------- shims
+class DotMap(dict):
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def toDict(self):
+        return {k: (v.toDict() if isinstance(v, DotMap) else v) for k, v in self.items()}
+
+
+class Conf:
+    """Minimal stand-in for pyhocon.ConfigTree (accessors used at reference models.py:21-83,
+    resnetfc.py:189-205, encoder.py:176-186, nerf.py:347-358, code.py:45-52)."""
+    _MISSING = object()
+
+    def __init__(self, d):
+        self.d = d
+
+    def _get(self, key, default=_MISSING):
+        cur = self.d
+        for part in key.split("."):
+            if isinstance(cur, dict) and part in cur:
+                cur = cur[part]
+            else:
+                if default is Conf._MISSING:
+                    raise KeyError(key)
+                return default
+        return cur
+
+    def __getitem__(self, key):
+        v = self._get(key)
+        return Conf(v) if isinstance(v, dict) else v
+
+    def get_bool(self, k, default=_MISSING):
+        return bool(self._get(k, default))
+
+    def get_int(self, k, default=_MISSING):
+        v = self._get(k, default)
+        return v if v is None else int(v)
+
+    def get_float(self, k, default=_MISSING):
+        v = self._get(k, default)
+        return v if v is None else float(v)
+
+    def get_string(self, k, default=_MISSING):
+        return self._get(k, default)
+
+    def get_list(self, k, default=_MISSING):
+        return self._get(k, default)
+
+
+def _basic_block(cin, cout, stride, norm_layer):
+    class BasicBlock(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+            self.bn1 = norm_layer(cout)
+            self.relu = nn.ReLU(inplace=True)
+            self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+            self.bn2 = norm_layer(cout)
+            self.downsample = None
+            if stride != 1 or cin != cout:
+                self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), norm_layer(cout))
+
+        def forward(self, x):
+            idt = x if self.downsample is None else self.downsample(x)
+            out = self.relu(self.bn1(self.conv1(x)))
+            out = self.bn2(self.conv2(out))
+            return self.relu(out + idt)
+
+    return BasicBlock()
+
+
+class ResNet34Skeleton(nn.Module):
+    """Public ResNet-34 layout (module structure only; see header)."""
+
+    def __init__(self, pretrained=False, norm_layer=None):
+        super().__init__()
+        assert not pretrained, "no pretrained weights offline"
+        norm_layer = norm_layer or nn.BatchNorm2d
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = norm_layer(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        cin = 64
+        for li, (cout, n) in enumerate([(64, 3), (128, 4), (256, 6), (512, 3)], start=1):
+            blocks = []
+            for b in range(n):
+                blocks.append(_basic_block(cin if b == 0 else cout, cout, (2 if (b == 0 and li > 1) else 1), norm_layer))
+            setattr(self, "layer%d" % li, nn.Sequential(*blocks))
+            cin = cout
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.fc = nn.Linear(512, 1000)
+
+
+def install_shims():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    mod("cv2", COLORMAP_HOT=0)
+    tv_models = mod("torchvision.models", resnet34=ResNet34Skeleton)
+    tv_tf = mod("torchvision.transforms")
+    mod("torchvision", models=tv_models, transforms=tv_tf)
+    mod("dotmap", DotMap=DotMap)
+    mod("pyhocon", ConfigFactory=object)
+
+    class _NoYolo(nn.Module):
+        def __init__(self, *a, **k):
+            raise RuntimeError("NeRF-YOLO models.yolo.Model is not available in this container")
+
+    mod("models")
+    mod("models.yolo", Model=_NoYolo)
+    sys.path.insert(0, REF_SRC)
+
+
+# --------------------------------------------------------------------------- configs
+def model_conf(backbone="resnet34", yolo=False, n_blocks=5, combine_layer=3, has_fine=True):
+    mlp = {"type": "resnet", "n_blocks": n_blocks, "d_hidden": 512, "combine_layer": combine_layer,
+           "combine_type": "average", "d_out": 4}
+    c = {
+        "use_encoder": True, "use_global_encoder": False, "use_xyz": True, "canon_xyz": False,
+        "use_code": True, "code": {"num_freqs": 6, "freq_factor": 1.5, "include_input": True},
+        "use_viewdirs": True, "use_code_viewdirs": False,
+        "mlp_coarse": dict(mlp), "mlp_fine": dict(mlp) if has_fine else {"type": "empty"},
+        "encoder": {"backbone": backbone, "pretrained": False, "num_layers": 4, "index_padding": "zeros"},
+    }
+    if yolo:
+        c["mlp_coarse"].update({"d_out": 7, "num_scales": 1, "num_anchors_per_scale": 3, "yolo": True})
+    return Conf(c)
+
+
+def load_mlp(mlp, seed, d_latent, d_out):
+    sd = synth.mlp_state(seed, d_latent=d_latent, d_out=d_out)
+    mlp.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+
+
+class Recorder:
+    """Records every random draw the renderer makes (they are inputs of the path: SURVEY.md 7
+    hard part 4) and every model call's output."""
+
+    def __init__(self):
+        self.draws = []
+        self._orig = {}
+
+    def __enter__(self):
+        for name in ("rand", "rand_like", "randn_like"):
+            self._orig[name] = getattr(torch, name)
+
+            def wrapped(*a, _n=name, **k):
+                out = self._orig[_n](*a, **k)
+                self.draws.append((_n, out.clone()))
+                return out
+
+            setattr(torch, name, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        for name, fn in self._orig.items():
+            setattr(torch, name, fn)
+
+
+def record_model_calls(net):
+    calls = []
+    orig = net.forward
+
+    def fwd(xyz, coarse=True, viewdirs=None, far=False):
+        out = orig(xyz, coarse=coarse, viewdirs=viewdirs, far=far)
+        calls.append((bool(coarse), out.detach().clone()))
+        return out
+
+    net.forward = fwd
+    return calls
+
+
+def pick_rays(all_rays, n, seed):
+    """A deterministic subset: centre crop + random others."""
+    H, W, _ = all_rays.shape
+    rs = np.random.RandomState(seed)
+    ys, xs = np.meshgrid(np.arange(H // 2 - 3, H // 2 + 3), np.arange(W // 2 - 3, W // 2 + 3), indexing="ij")
+    idx = (ys * W + xs).reshape(-1)
+    rest = rs.choice(H * W, size=n - idx.size, replace=False)
+    idx = np.concatenate([idx, rest])
+    return all_rays.reshape(-1, 8)[idx], idx.astype(np.int64)
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+# --------------------------------------------------------------------------- fixtures
+def fixture_nerf(name, H, NS, Kc, Kf, Kfd, n_rays, seed, ebs):
+    import util
+    from model import make_model
+    from render import NeRFRenderer
+
+    torch.manual_seed(seed)
+    W = H
+    focal = torch.tensor(131.25 * H / 128.0)
+    c_img = torch.tensor([W * 0.5, H * 0.5])
+    z_near, z_far = 0.8, 1.8
+    conf = model_conf(has_fine=Kf > 0)
+    net = make_model(conf).eval()
+    load_mlp(net.mlp_coarse, seed * 10 + 1, 512, 4)
+    if Kf > 0:
+        load_mlp(net.mlp_fine, seed * 10 + 2, 512, 4)
+
+    src_poses, tgt_pose = synth.scene_cameras(NS)
+    Hl, Wl = H // 2, W // 2
+    lat = synth.latent(seed * 10 + 3, NS, 512, Hl, Wl)
+    images = torch.zeros(1, NS, 3, H, W)
+
+    # encode(): run the reference's pose / intrinsics handling, but bypass the conv trunk by
+    # replacing the encoder's forward with one that installs the seeded latent exactly as
+    # SpatialEncoder.forward does at reference encoder.py:169-172.
+    enc = net.encoder
+
+    def fake_forward(x):
+        enc.latent = torch.from_numpy(lat)
+        enc.latent_scaling[0] = enc.latent.shape[-1]
+        enc.latent_scaling[1] = enc.latent.shape[-2]
+        enc.latent_scaling = enc.latent_scaling / (enc.latent_scaling - 1) * 2.0
+        return enc.latent
+
+    enc.forward = fake_forward
+    net.encode(images, torch.from_numpy(src_poses)[None], focal, c=c_img[None])
+
+    all_rays = util.gen_rays(torch.from_numpy(tgt_pose)[None], W, H, focal, z_near, z_far, c=c_img)[0]
+    rays, ray_idx = pick_rays(all_rays, n_rays, seed)
+
+    renderer = NeRFRenderer(n_coarse=Kc, n_fine=Kf, n_fine_depth=Kfd, depth_std=0.01,
+                            white_bkgd=True, eval_batch_size=ebs).eval()
+    calls = record_model_calls(net)
+    with torch.no_grad(), Recorder() as rec:
+        out = renderer(net, rays[None], want_weights=True)
+
+    d = {
+        "H": H, "W": W, "NS": NS, "Kc": Kc, "Kf": Kf, "Kfd": Kfd, "seed": seed,
+        "focal": np_(focal), "c": np_(c_img), "z_near": z_near, "z_far": z_far,
+        "src_poses": src_poses, "tgt_pose": tgt_pose, "rays": np_(rays), "ray_idx": ray_idx,
+        "all_rays_corner": np_(all_rays[:2, :3]),
+        "enc_poses": np_(net.poses), "enc_focal": np_(net.focal), "enc_c": np_(net.c),
+        "latent_scaling": np_(enc.latent_scaling),
+        "coarse_rgb": np_(out.coarse.rgb[0]), "coarse_depth": np_(out.coarse.depth[0]),
+        "coarse_weights": np_(out.coarse.weights[0]),
+    }
+    draws = rec.draws
+    d["u_coarse"] = np_(draws[0][1])
+    assert draws[0][0] == "rand_like" and draws[0][1].shape == (n_rays, Kc)
+    coarse_calls = torch.cat([o for (cflag, o) in calls if cflag], dim=1)[0]
+    d["coarse_out"] = np_(coarse_calls)  # (n_rays*Kc, 4) sigmoid(rgb), relu(sigma)
+    if Kf > 0:
+        i = 1
+        if Kf - Kfd > 0:
+            assert draws[1][0] == "rand" and draws[2][0] == "rand_like"
+            d["u_fine"] = np_(draws[1][1])
+            d["u_fine2"] = np_(draws[2][1])
+            i = 3
+        if Kfd > 0:
+            assert draws[i][0] == "randn_like"
+            d["g_depth"] = np_(draws[i][1])
+        fine_calls = torch.cat([o for (cflag, o) in calls if not cflag], dim=1)[0]
+        d["fine_out"] = np_(fine_calls)
+        d["fine_rgb"] = np_(out.fine.rgb[0])
+        d["fine_depth"] = np_(out.fine.depth[0])
+        d["fine_weights"] = np_(out.fine.weights[0])
+    # z_coarse re-derived by the reference's own sample_coarse on the recorded draw
+    with torch.no_grad():
+        orig = torch.rand_like
+        torch.rand_like = lambda x: draws[0][1]
+        d["z_coarse"] = np_(renderer.sample_coarse(rays))
+        torch.rand_like = orig
+
+    # direct model probe at the point the reference's own smoke test uses
+    # (test/model_encode.py:79-81) plus random points, NS views
+    rs = np.random.RandomState(seed + 77)
+    pts = rs.uniform(-0.6, 0.6, size=(1, 41, 3)).astype(np.float32)
+    pts[0, 0] = [5.26, -0.83, -0.18]
+    vd = rs.standard_normal((1, 41, 3)).astype(np.float32)
+    vd /= np.linalg.norm(vd, axis=-1, keepdims=True)
+    vd[0, 0] = 0.0
+    with torch.no_grad():
+        d["probe_xyz"] = pts[0]
+        d["probe_viewdirs"] = vd[0]
+        d["probe_out_coarse"] = np_(net(torch.from_numpy(pts), coarse=True, viewdirs=torch.from_numpy(vd)))[0]
+        if Kf > 0:
+            d["probe_out_fine"] = np_(net(torch.from_numpy(pts), coarse=False, viewdirs=torch.from_numpy(vd)))[0]
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print("wrote", name, {k: getattr(v, "shape", v) for k, v in d.items() if k in ("rays", "coarse_out", "fine_rgb")})
+
+
+def fixture_yolo(name, seed, n_rays=40, K=128, ebs=128):
+    """YOLO mode: gen_rays_yolo, world->cam poses used as given, raw 21-vector MLP output,
+    YoloRenderer aggregation (reference yolo.py:37-114, models.py:119-120,222-224,254-264)."""
+    import util
+    import model.encoder as enc_mod
+    from model import make_model
+    from render.yolo import YoloRenderer
+
+    torch.manual_seed(seed)
+
+    class DummyYolo(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.dims = [1792]
+
+    enc_mod.YOLOEncoder = DummyYolo
+    conf = model_conf(backbone="custom", yolo=True, has_fine=False)
+    net = make_model(conf).eval()
+    load_mlp(net.mlp_coarse, seed * 10 + 1, 1792, 21)
+    NS, H, W = 3, 128, 128
+    Hl, Wl = 16, 16
+    lat = synth.latent(seed * 10 + 3, NS, 1792, Hl, Wl)
+    enc = net.encoder
+
+    def fake_forward(x):
+        enc.latent = torch.from_numpy(lat)
+        enc.latent_scaling[0] = enc.latent.shape[-1]
+        enc.latent_scaling[1] = enc.latent.shape[-2]
+        enc.latent_scaling = enc.latent_scaling / (enc.latent_scaling - 1) * 2.0
+        return enc.latent
+
+    enc.forward = fake_forward
+    # world->cam extrinsics: cameras on a circle looking at the origin, +z forward (OpenCV-like)
+    src_c2w, tgt_c2w = synth.scene_cameras(NS, radius=6.0, phi=-25.0)
+    flipyz = np.diag([1.0, -1.0, -1.0, 1.0]).astype(np.float32)
+    src_w2c = np.stack([np.linalg.inv(p @ flipyz) for p in src_c2w]).astype(np.float32)
+    tgt_w2c = np.linalg.inv(tgt_c2w @ flipyz).astype(np.float32)
+    focal = torch.tensor([140.0, 150.0])
+    c_img = torch.tensor([64.0, 60.0])
+    net.encode(torch.zeros(1, NS, 3, H, W), torch.from_numpy(src_w2c)[None], focal[None], c=c_img[None])
+
+    Wc, Hc = 16, 12
+    rays_all = util.gen_rays_yolo(torch.from_numpy(tgt_w2c)[None], Wc, Hc, focal / 8, c_img / 8, 1.0, 13.0)
+    rays = rays_all.reshape(-1, 8)[:n_rays]
+    # include the reference test's hard-coded probe rays (test/yolo_renderer.py:12-15)
+    rays = torch.cat([rays, torch.tensor([[1, 2, 3, 4, 5, 6, 0.1, 10], [0, 0, 0, 0, 1, 2, 0.1, 10]], dtype=torch.float32)])
+    renderer = YoloRenderer(K, ebs, 1, 3)
+    renderer.bind_parallel(net)
+    calls = record_model_calls(net)
+    with torch.no_grad(), Recorder() as rec:
+        out = renderer(rays[None])
+    d = {
+        "seed": seed, "NS": NS, "H": H, "W": W, "K": K, "Hl": Hl, "Wl": Wl,
+        "focal": np_(focal), "c": np_(c_img), "src_w2c": src_w2c, "tgt_w2c": tgt_w2c,
+        "Wc": Wc, "Hc": Hc, "rays_all": np_(rays_all[0]), "rays": np_(rays),
+        "u_coarse": np_(rec.draws[0][1]),
+        "raw_out": np_(torch.cat([o for (_, o) in calls], dim=1)[0]),
+        "yolo_out": np_(out),
+        "enc_poses": np_(net.poses), "enc_focal": np_(net.focal), "enc_c": np_(net.c),
+    }
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print("wrote", name, d["raw_out"].shape, d["yolo_out"].shape)
+
+
+def fixture_encoder(name, seed, NS=2, H=64, W=48):
+    """SpatialEncoder.forward (reference encoder.py:110-173) over the ResNet-34 skeleton with
+    seeded random weights, eval-mode batch norm."""
+    from model.encoder import SpatialEncoder
+
+    torch.manual_seed(seed)
+    enc = SpatialEncoder(backbone="resnet34", pretrained=False, num_layers=4, index_padding="zeros").eval()
+    sd = synth.resnet34_state(seed * 10 + 5, prefix="model.")
+    missing = enc.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert all(k.startswith(("model.layer4", "model.fc")) or "num_batches_tracked" in k for k in missing.missing_keys), missing
+    img = synth.images(seed * 10 + 6, NS, H, W)
+    with torch.no_grad():
+        lat = enc(torch.from_numpy(img))
+        levels = [np_(t) for t in enc.latents]
+    # index(): bilinear lookup incl. out-of-image points (zeros padding), reference encoder.py:79-108
+    rs = np.random.RandomState(seed)
+    uv = rs.uniform(-8.0, max(H, W) + 8.0, size=(NS, 50, 2)).astype(np.float32)
+    with torch.no_grad():
+        samp = enc.index(torch.from_numpy(uv), None, torch.tensor([float(W), float(H)]))
+    d = {"seed": seed, "NS": NS, "H": H, "W": W, "latent": np_(lat), "latent_scaling": np_(enc.latent_scaling),
+         "level1": levels[1][:, :8], "level3": levels[3][:, :8], "uv": uv, "index_out": np_(samp)}
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print("wrote", name, d["latent"].shape)
+
+
+def fixture_rays(name):
+    """util.gen_rays / gen_rays_yolo (reference util.py:240-278, 808-876) incl. the probe call of
+    the reference's own smoke test (test/gen_rays_render.py:82)."""
+    import util
+
+    poses = torch.from_numpy(np.stack([synth.pose_spherical(30, -20, 1.3), synth.pose_spherical(200, -35, 2.0)]))
+    r1 = util.gen_rays(poses, 20, 12, torch.tensor(35.5), 0.8, 1.8, c=None)
+    r2 = util.gen_rays(poses[:1], 16, 16, torch.tensor([30.0, 28.0]), 0.5, 2.5, c=torch.tensor([7.5, 9.25]))
+    flipyz = np.diag([1.0, -1.0, -1.0, 1.0]).astype(np.float32)
+    w2c = torch.from_numpy(np.stack([np.linalg.inv(p.numpy() @ flipyz) for p in poses]).astype(np.float32))
+    focal = torch.tensor([1450.0, 1460.0])
+    cc = torch.tensor([960.0, 540.0])
+    r3 = util.gen_rays_yolo(w2c, 48, 27, focal / 10, cc / 10, 5.0, 10.0)
+    d = {"poses": np_(poses), "r1": np_(r1), "r2": np_(r2), "w2c": np_(w2c), "yolo_focal": np_(focal / 10),
+         "yolo_c": np_(cc / 10), "r3": np_(r3)}
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print("wrote", name, r1.shape, r2.shape, r3.shape)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    install_shims()
+    fixture_rays("rays")
+    # C1-like: single view, coarse only (BASELINE config 1 at reduced ray count)
+    fixture_nerf("nerf_c1", H=64, NS=1, Kc=32, Kf=0, Kfd=0, n_rays=80, seed=1, ebs=1000)
+    # C2-like: 3 views, 64 coarse + 32 fine (16 depth), chunked model calls
+    fixture_nerf("nerf_c2", H=128, NS=3, Kc=64, Kf=32, Kfd=16, n_rays=100, seed=7, ebs=3000)
+    fixture_yolo("yolo_c3", seed=3)
+    fixture_encoder("encoder", seed=4)
+
+
+if __name__ == "__main__":
+    main()
