@@ -1,0 +1,360 @@
+"""
+ORACLE -- TEST INFRASTRUCTURE ONLY.  A CPU restatement (torch CPU tensors used as a plain
+fp32 array library) of the pixelNeRF-YOLO rendering hot path of kofinandi/pixel-nerf-yolo.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this file,
+and only as the checker / the timed CPU baseline -- never as a product path.  The product
+(pixel-nerf-yolo_amd/) fails loudly when libpnyolo.so or a GPU is missing; it never falls
+back to this code.
+
+Pinning: every function below is checked in tests/test_oracle_golden.py against fixtures
+captured by tools/make_golden.py from the reference itself imported on CPU in the build
+container (the reference has no golden vectors of its own).  Two boundaries stay
+PARITY UNPINNED because the third-party code is absent from the container: torchvision's
+ResNet-34 definition (restated from the public architecture, arithmetic = torch conv2d /
+batch_norm) and the NeRF-YOLO `models.yolo.Model` backbone (its output, the latent, is an
+input here).
+
+Each function cites the reference file:line (relative to /root/reference) it follows.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+f32 = torch.float32
+
+
+def T(x):
+    return torch.as_tensor(x, dtype=f32)
+
+
+# ----------------------------------------------------------------------------- rays
+def gen_rays(poses, width, height, focal, z_near, z_far, c=None):
+    """src/util/util.py:115-145 (unproj_map) + :240-278 (gen_rays), ndc branch dead.
+    poses (B,4,4) cam->world; focal scalar or (fx,fy); c (cx,cy) or None -> image centre.
+    Pixel coordinates are integers (no +0.5); camera looks down -z; dirs are unit length."""
+    poses = T(poses)
+    focal = T(focal).reshape(-1)
+    fx, fy = (float(focal[0]), float(focal[0])) if focal.numel() == 1 else (float(focal[0]), float(focal[1]))
+    if c is None:
+        cx, cy = width * 0.5, height * 0.5
+    else:
+        c = T(c).reshape(-1)
+        cx, cy = float(c[0]), float(c[1])
+    ys = (torch.arange(height, dtype=f32) - cy) / fy
+    xs = (torch.arange(width, dtype=f32) - cx) / fx
+    Y = ys[:, None].expand(height, width)
+    X = xs[None, :].expand(height, width)
+    d = torch.stack((X, -Y, -torch.ones_like(X)), dim=-1)
+    d = d / torch.norm(d, dim=-1, keepdim=True)
+    B = poses.shape[0]
+    R = poses[:, :3, :3]
+    dirs = torch.einsum("bij,hwj->bhwi", R, d)
+    orig = poses[:, None, None, :3, 3].expand(B, height, width, 3)
+    near = torch.full((B, height, width, 1), float(z_near), dtype=f32)
+    far = torch.full((B, height, width, 1), float(z_far), dtype=f32)
+    return torch.cat((orig, dirs, near, far), dim=-1)
+
+
+def gen_rays_yolo(poses, width, height, focal, c, z_near, z_far):
+    """src/util/util.py:808-876.  poses (B,4,4) WORLD->cam extrinsics; direction =
+    inv(E)[:3,:3] . K^-1 [x+0.49, y+0.49, 1] (not normalised, +z forward); origin = inv(E)[:3,3].
+    The reference builds a (W,H) grid and permutes to (H,W)."""
+    poses = T(poses)
+    focal = T(focal).reshape(-1)
+    c = T(c).reshape(-1)
+    K = torch.tensor([[focal[0], 0, c[0]], [0, focal[1], c[1]], [0, 0, 1]], dtype=f32)
+    Kinv = torch.inverse(K)
+    xs = torch.linspace(0, width - 1, width) + 0.49
+    ys = torch.linspace(0, height - 1, height) + 0.49
+    gx = xs[None, :].expand(height, width)
+    gy = ys[:, None].expand(height, width)
+    pix = torch.stack((gx, gy, torch.ones_like(gx)), dim=-1)  # (H,W,3)
+    dcam = torch.einsum("ij,hwj->hwi", Kinv, pix)
+    out = []
+    for b in range(poses.shape[0]):
+        Einv = torch.inverse(poses[b])
+        dw = torch.einsum("ij,hwj->hwi", Einv[:3, :3], dcam)
+        o = Einv[:3, 3][None, None].expand(height, width, 3)
+        near = torch.full((height, width, 1), float(z_near), dtype=f32)
+        far = torch.full((height, width, 1), float(z_far), dtype=f32)
+        out.append(torch.cat((o, dw, near, far), dim=-1))
+    return torch.stack(out)
+
+
+# ----------------------------------------------------------------------------- sampling
+def sample_coarse(rays, n_coarse, u, lindisp=False):
+    """src/render/nerf.py:104-121 (same arithmetic in src/render/yolo.py:15-26).
+    u (N,Kc) ~ U[0,1) is the renderer's first random draw (unconditional, also in eval)."""
+    near, far = rays[:, 6:7], rays[:, 7:8]
+    step = 1.0 / n_coarse
+    t = torch.linspace(0, 1 - step, n_coarse, dtype=f32)[None, :].repeat(rays.shape[0], 1)
+    t = t + T(u) * step
+    if not lindisp:
+        return near * (1 - t) + far * t
+    return 1 / (1 / near * (1 - t) + 1 / far * t)
+
+
+def sample_fine(rays, weights, u, u2, n_coarse, lindisp=False):
+    """src/render/nerf.py:126-154.  u, u2 (N, Kf-Kfd): the 2nd and 3rd random draws."""
+    w = weights + 1e-5
+    pdf = w / torch.sum(w, -1, keepdim=True)
+    cdf = torch.cumsum(pdf, -1)
+    cdf = torch.cat([torch.zeros_like(cdf[:, :1]), cdf], -1)
+    inds = torch.searchsorted(cdf, T(u).contiguous(), right=True).float() - 1.0
+    inds = torch.clamp_min(inds, 0.0)
+    t = (inds + T(u2)) / n_coarse
+    near, far = rays[:, 6:7], rays[:, 7:8]
+    if not lindisp:
+        return near * (1 - t) + far * t
+    return 1 / (1 / near * (1 - t) + 1 / far * t)
+
+
+def sample_fine_depth(rays, depth, g, depth_std):
+    """src/render/nerf.py:156-167.  g (N,Kfd) ~ N(0,1): the 4th random draw."""
+    z = depth[:, None].repeat(1, g.shape[1])
+    z = z + T(g) * depth_std
+    return torch.max(torch.min(z, rays[:, 7:8]), rays[:, 6:7])
+
+
+def composite(rays, z, out, white_bkgd):
+    """src/render/nerf.py:184-188 (deltas, last = far - z_last) and :229-250
+    (alpha, shifted cumprod transmittance, weights, rgb/depth sums, white background).
+    out (N,K,4) = per-sample [sigmoid rgb, relu sigma] from the model."""
+    deltas = torch.cat([z[:, 1:] - z[:, :-1], rays[:, 7:8] - z[:, -1:]], -1)
+    rgbs, sigmas = out[..., :3], out[..., 3]
+    alphas = 1 - torch.exp(-deltas * torch.relu(sigmas))
+    shifted = torch.cat([torch.ones_like(alphas[:, :1]), 1 - alphas + 1e-10], -1)
+    Tr = torch.cumprod(shifted, -1)
+    weights = alphas * Tr[:, :-1]
+    rgb = torch.sum(weights.unsqueeze(-1) * rgbs, -2)
+    depth = torch.sum(weights * z, -1)
+    if white_bkgd:
+        rgb = rgb + 1 - weights.sum(dim=1).unsqueeze(-1)
+    return weights, rgb, depth
+
+
+def yolo_aggregate(out, n_anchors=3):
+    """src/render/yolo.py:96-114.  out (N,K,A*7) raw -> (N,A,7) = [max_k p, sum_k p*v/(sum_k p+1e-5)]."""
+    N, K, _ = out.shape
+    o = out.reshape(N, K, n_anchors, 7)
+    p = torch.sigmoid(o[..., 0])
+    ps = p.sum(dim=1)
+    v = (o[..., 1:] * p.unsqueeze(-1)).sum(dim=1) / (ps.unsqueeze(-1) + 1e-5)
+    return torch.cat([p.max(dim=1)[0].unsqueeze(-1), v], dim=-1)
+
+
+# ----------------------------------------------------------------------------- model pieces
+def positional_encoding(x, num_freqs=6, freq_factor=1.5):
+    """src/model/code.py:11-42: out = [x, sin(f0 x), sin(f0 x + pi/2), sin(f1 x), ...] with the
+    argument formed as fp32 (phase + x*freq); cos is obtained as sin(. + pi/2)."""
+    freqs = freq_factor * 2.0 ** torch.arange(0, num_freqs)
+    fr = torch.repeat_interleave(freqs, 2).view(1, -1, 1).to(f32)
+    ph = torch.zeros(2 * num_freqs)
+    ph[1::2] = math.pi * 0.5
+    ph = ph.view(1, -1, 1).to(f32)
+    e = x.unsqueeze(1).repeat(1, num_freqs * 2, 1)
+    e = torch.sin(ph + e * fr)
+    return torch.cat((x, e.view(x.shape[0], -1)), dim=-1)
+
+
+def encode_cameras(poses, focal, c, width, height, yolo=False):
+    """src/model/models.py:115-148: cam->world poses inverted analytically to world->cam
+    [R^T | -R^T t] (YOLO mode: extrinsics used as given); focal -> (.,2) with fy negated
+    (non-YOLO); principal point defaults to the image centre."""
+    poses = T(poses).reshape(-1, 4, 4)
+    if not yolo:
+        rot = poses[:, :3, :3].transpose(1, 2)
+        trans = -torch.bmm(rot, poses[:, :3, 3:])
+        w2c = torch.cat((rot, trans), dim=-1)
+    else:
+        w2c = poses[:, :3, :4].clone()
+    focal = T(focal)
+    if focal.dim() == 0:
+        focal = focal[None, None].repeat(1, 2)
+    elif focal.dim() == 1:
+        focal = focal.unsqueeze(-1).repeat(1, 2)
+    else:
+        focal = focal.clone()
+    if not yolo:
+        focal[..., 1] *= -1.0
+    if c is None:
+        c = torch.tensor([[width * 0.5, height * 0.5]], dtype=f32)
+    else:
+        c = T(c)
+        if c.dim() == 0:
+            c = c[None, None].repeat(1, 2)
+        elif c.dim() == 1:
+            c = c.unsqueeze(-1).repeat(1, 2)
+    return w2c, focal, c
+
+
+def index_latent(latent, uv, width, height):
+    """src/model/encoder.py:79-108 with index_padding=zeros (conf/default.conf:49),
+    align_corners=True, bilinear.  latent (NS,L,Hl,Wl); uv (NS,P,2) in image pixels.
+    Returns (NS,P,L).  The bilinear lookup (F.grid_sample in the reference) is written out
+    tap by tap: unnormalise ((g+1)/2)*(size-1), floor, 4 weighted taps, out-of-range taps = 0."""
+    NS, L, Hl, Wl = latent.shape
+    ls = torch.tensor([Wl, Hl], dtype=f32)
+    ls = ls / (ls - 1) * 2.0  # latent_scaling, encoder.py:170-172 (fp32 arithmetic)
+    scale = ls / torch.tensor([width, height], dtype=f32)
+    g = uv * scale - 1.0
+    ix = ((g[..., 0] + 1) / 2) * (Wl - 1)
+    iy = ((g[..., 1] + 1) / 2) * (Hl - 1)
+    x0 = torch.floor(ix)
+    y0 = torch.floor(iy)
+    x1, y1 = x0 + 1, y0 + 1
+    w_nw = (x1 - ix) * (y1 - iy)
+    w_ne = (ix - x0) * (y1 - iy)
+    w_sw = (x1 - ix) * (iy - y0)
+    w_se = (ix - x0) * (iy - y0)
+    lat = latent.permute(0, 2, 3, 1).reshape(NS, Hl * Wl, L)
+
+    def tap(xi, yi, w):
+        ok = (xi >= 0) & (xi <= Wl - 1) & (yi >= 0) & (yi <= Hl - 1)
+        idx = (yi.clamp(0, Hl - 1) * Wl + xi.clamp(0, Wl - 1)).long()
+        v = torch.gather(lat, 1, idx.unsqueeze(-1).expand(-1, -1, L))
+        return v * (w * ok.to(f32)).unsqueeze(-1)
+
+    return tap(x0, y0, w_nw) + tap(x1, y0, w_ne) + tap(x0, y1, w_sw) + tap(x1, y1, w_se)
+
+
+def _lin(sd, name, x):
+    return torch.addmm(sd[name + ".bias"], x, sd[name + ".weight"].t())
+
+
+def resnetfc(sd, z, x, ns, n_blocks=5, combine_layer=3):
+    """src/model/resnetfc.py:134-186 (+ :53-62 block, util.py:489-499 combine):
+    rows ordered view-major within a scene: row = v*B + b.  z (ns*B,L), x (ns*B,d_in)."""
+    h = _lin(sd, "lin_in", x)
+    for blk in range(n_blocks):
+        if blk == combine_layer:
+            h = h.reshape(ns, -1, h.shape[-1]).mean(dim=0)
+        if blk < combine_layer:
+            h = h + _lin(sd, "lin_z.%d" % blk, z)
+        net = _lin(sd, "blocks.%d.fc_0" % blk, torch.relu(h))
+        dx = _lin(sd, "blocks.%d.fc_1" % blk, torch.relu(net))
+        h = h + dx
+    return _lin(sd, "lin_out", torch.relu(h))
+
+
+class Scene:
+    """Per-scene state the reference keeps in module buffers after encode()
+    (src/model/models.py:74-87,114-148; src/model/encoder.py:73-76,169-172)."""
+
+    def __init__(self, mlp_coarse, mlp_fine, latent, poses, focal, c, width, height, yolo=False,
+                 n_blocks=5, combine_layer=3):
+        self.mlp_coarse = {k: T(v) for k, v in mlp_coarse.items()}
+        self.mlp_fine = None if mlp_fine is None else {k: T(v) for k, v in mlp_fine.items()}
+        self.latent = T(latent)
+        self.w2c, self.focal, self.c = encode_cameras(poses, focal, c, width, height, yolo)
+        self.width, self.height = width, height
+        self.yolo = yolo
+        self.ns = self.latent.shape[0]
+        self.n_blocks, self.combine_layer = n_blocks, combine_layer
+
+
+def query(scene, xyz, viewdirs, coarse=True):
+    """src/model/models.py:153-318 for SB=1 with the shipped flags (use_xyz, normalize_z,
+    use_code, use_viewdirs, not use_code_viewdirs).  xyz, viewdirs (B,3) -> (B,d_out):
+    [sigmoid rgb, relu sigma], or the raw vector in YOLO mode."""
+    xyz, viewdirs = T(xyz), T(viewdirs)
+    ns, B = scene.ns, xyz.shape[0]
+    R, t = scene.w2c[:, :, :3], scene.w2c[:, :, 3]
+    xr = torch.matmul(R[:, None], xyz[None, :, :, None])[..., 0]  # (ns,B,3) rotation only
+    xc = xr + t[:, None]
+    code = positional_encoding(xr.reshape(-1, 3))
+    vd = torch.matmul(R[:, None], viewdirs[None, :, :, None])[..., 0].reshape(-1, 3)
+    x_in = torch.cat((code, vd), dim=1)
+    if not scene.yolo:
+        uv = -xc[:, :, :2] / xc[:, :, 2:]
+    else:
+        uv = xc[:, :, :2] / xc[:, :, 2:]
+    foc = scene.focal if scene.focal.shape[0] > 1 else scene.focal.expand(ns, 2)
+    cc = scene.c if scene.c.shape[0] > 1 else scene.c.expand(ns, 2)
+    uv = uv * foc[:, None] + cc[:, None]
+    lat = index_latent(scene.latent, uv, scene.width, scene.height).reshape(ns * B, -1)
+    if scene.yolo:
+        behind = (xc[:, :, 2] >= 0).reshape(-1, 1)  # models.py:224,254-264: zero where z >= 0 or NaN
+        lat = torch.where(behind | torch.isnan(lat), torch.zeros_like(lat), lat)
+    sd = scene.mlp_coarse if (coarse or scene.mlp_fine is None) else scene.mlp_fine
+    out = resnetfc(sd, lat, x_in, ns, scene.n_blocks, scene.combine_layer)
+    if scene.yolo:
+        return out
+    return torch.cat([torch.sigmoid(out[:, :3]), torch.relu(out[:, 3:4])], dim=-1)
+
+
+def _query_rays(scene, rays, z, coarse, chunk):
+    N, K = z.shape
+    pts = (rays[:, None, :3] + z.unsqueeze(2) * rays[:, None, 3:6]).reshape(-1, 3)
+    dirs = rays[:, None, 3:6].expand(-1, K, -1).reshape(-1, 3)
+    outs = [query(scene, pts[i:i + chunk], dirs[i:i + chunk], coarse) for i in range(0, pts.shape[0], chunk)]
+    return torch.cat(outs, 0).reshape(N, K, -1)
+
+
+def render(scene, rays, n_coarse, n_fine, n_fine_depth, u_coarse, u_fine=None, u_fine2=None, g_depth=None,
+           depth_std=0.01, white_bkgd=True, lindisp=False, chunk=50000):
+    """src/render/nerf.py:257-309 (forward) for SB=1: coarse pass, then fine pass on
+    sort(cat(z_coarse, z_fine, z_depth)) with the fine MLP.  The four random draws are inputs."""
+    rays = T(rays)
+    res = {}
+    zc = sample_coarse(rays, n_coarse, u_coarse, lindisp)
+    oc = _query_rays(scene, rays, zc, True, chunk)
+    wc, rgbc, dc = composite(rays, zc, oc, white_bkgd)
+    res["coarse"] = dict(z=zc, out=oc, weights=wc, rgb=rgbc, depth=dc)
+    if n_fine > 0:
+        samps = [zc]
+        if n_fine - n_fine_depth > 0:
+            samps.append(sample_fine(rays, wc, u_fine, u_fine2, n_coarse, lindisp))
+        if n_fine_depth > 0:
+            samps.append(sample_fine_depth(rays, dc, g_depth, depth_std))
+        zf, _ = torch.sort(torch.cat(samps, dim=-1), dim=-1)
+        of = _query_rays(scene, rays, zf, False, chunk)
+        wf, rgbf, df = composite(rays, zf, of, white_bkgd)
+        res["fine"] = dict(z=zf, out=of, weights=wf, rgb=rgbf, depth=df)
+    return res
+
+
+def yolo_render(scene, rays, n_coarse, u_coarse, n_anchors=3, chunk=50000):
+    """src/render/yolo.py:37-114: coarse sampling only, raw MLP vectors, probability-weighted
+    aggregation along each ray."""
+    rays = T(rays)
+    z = sample_coarse(rays, n_coarse, u_coarse)
+    raw = _query_rays(scene, rays, z, True, chunk)
+    return dict(z=z, raw=raw, out=yolo_aggregate(raw, n_anchors))
+
+
+# ----------------------------------------------------------------------------- encoder
+def _bn(sd, name, x):
+    return F.batch_norm(x, sd[name + ".running_mean"], sd[name + ".running_var"], sd[name + ".weight"],
+                        sd[name + ".bias"], training=False, eps=1e-5)
+
+
+def _block(sd, p, x, stride):
+    idt = x
+    if (p + "downsample.0.weight") in sd:
+        idt = _bn(sd, p + "downsample.1", F.conv2d(x, sd[p + "downsample.0.weight"], stride=stride))
+    out = torch.relu(_bn(sd, p + "bn1", F.conv2d(x, sd[p + "conv1.weight"], stride=stride, padding=1)))
+    out = _bn(sd, p + "bn2", F.conv2d(out, sd[p + "conv2.weight"], padding=1))
+    return torch.relu(out + idt)
+
+
+def spatial_encoder(sd, images, prefix="encoder.model."):
+    """src/model/encoder.py:139-173 with num_layers=4, use_first_pool, eval-mode batch norm:
+    conv1/bn1/relu -> L0; maxpool, layer1 -> L1; layer2 -> L2; layer3 -> L3; every level
+    bilinearly upsampled (align_corners=True) to L0's size; channel concat (64+64+128+256).
+    ResNet-34 BasicBlock layout [3,4,6] restated from the public architecture (torchvision is
+    absent: PARITY UNPINNED at that boundary).  Returns (latent NCHW, [levels])."""
+    sd = {k[len(prefix):]: T(v) for k, v in sd.items() if k.startswith(prefix)}
+    x = T(images)
+    x = torch.relu(_bn(sd, "bn1", F.conv2d(x, sd["conv1.weight"], stride=2, padding=3)))
+    levels = [x]
+    x = F.max_pool2d(x, 3, 2, 1)
+    for li, n in ((1, 3), (2, 4), (3, 6)):
+        for b in range(n):
+            x = _block(sd, "layer%d.%d." % (li, b), x, 2 if (b == 0 and li > 1) else 1)
+        levels.append(x)
+    size = levels[0].shape[-2:]
+    ups = [F.interpolate(l, size, mode="bilinear", align_corners=True) for l in levels]
+    return torch.cat(ups, dim=1), levels

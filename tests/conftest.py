@@ -1,0 +1,31 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import pnyolo_pkg  # noqa: E402
+
+pnyolo_pkg.load()
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    cache = {}
+
+    def load(name):
+        if name not in cache:
+            with np.load(os.path.join(GOLDEN, name + ".npz")) as f:
+                cache[name] = {k: f[k] for k in f.files}
+        return cache[name]
+
+    return load
