@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""
+bench.py -- rays/sec of the pixelNeRF-YOLO rendering hot path on MI355X (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], "C2"): 128x128 render, 3 source views, ResNet-34 encoder,
+64 coarse + 32 fine samples (16 of them depth samples), white background; synthetic images,
+seeded random weights of the reference architecture, cameras on a sphere.
+A "step" = one full frame per rank (16384 rays resident in HBM -> rgb/depth in HBM): coarse
+sampling, fused MLP, composite, importance sampling + sort, fused MLP, composite, then (N > 1)
+one RCCL all-gather of the rendered (rays, 4) tiles.  Weak scaling: every rank renders its own
+frame; value = all rays of all ranks / max-over-ranks time.  The scene encode (ResNet-34 trunk)
+happens once per scene before the timed region and is reported as `encode_ms`.
+
+One JSON line on rank 0 with the contract fields plus
+  roofline:     dominant kernel = pny_mlp_kernel; achieved = algorithmic MLP FLOPs (2/MAC,
+                SURVEY.md 8d: 2.6218 GFLOP/ray) / its HIP-event time measured inside libpnyolo on
+                the launch stream; peak = 157.3 TFLOP/s exact-fp32 MFMA (the dtype issued).
+  cpu_baseline: the oracle (oracle/pnyolo_oracle.py, a port) timed on the host cores on a bounded
+                ray subset of the same frame.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "rays/sec (whole node), 64 samples/ray, 3-view 128×128 render"
+H = W = 128
+NS, KC, KF, KFD = 3, 64, 32, 16
+FOCAL, Z_NEAR, Z_FAR = 131.25, 0.8, 1.8
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def flop_per_ray():
+    per_vs = 42 * 512 + 3 * 512 * 512 + 6 * 512 * 512
+    post = 4 * 512 * 512 + 512 * 4
+    per_sample = 2 * (NS * per_vs + post)
+    return per_sample * (KC + (KC + KF))
+
+
+def describe():
+    return {
+        "metric": METRIC, "unit": "rays/s", "flop_per_ray": flop_per_ray(),
+        "config": {"workload": "C2: 128x128 render, 3 source views, ResNet34 encoder, 64 coarse + 32 fine "
+                               "(16 depth) samples, white bkgd", "rays_per_step_per_gpu": H * W},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cpu-rays", type=int, default=384, help="ray subset for the CPU baseline (0 = skip)")
+    ap.add_argument("--describe", action="store_true", help="print the workload description and exit (no GPU)")
+    args = ap.parse_args()
+    if args.describe:
+        print(json.dumps(describe()))
+        return
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import pnyolo_pkg
+    pnyolo_pkg.load()
+    from pixel_nerf_yolo_amd import conf as pconf, synth
+    from pixel_nerf_yolo_amd.model import make_model
+    from pixel_nerf_yolo_amd.render import NeRFRenderer
+    from pixel_nerf_yolo_amd.util import gen_rays
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path for the product)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- scene: weights, encoder, cameras
+    net = make_model(pconf.default_mv()["model"]).eval()
+    sd = {}
+    sd.update({"mlp_coarse." + k: v for k, v in synth.mlp_state(71).items()})
+    sd.update({"mlp_fine." + k: v for k, v in synth.mlp_state(72).items()})
+    sd.update(synth.resnet34_state(74))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    net = net.to(dev)
+    src, _ = synth.scene_cameras(NS)
+    tgt = synth.pose_spherical(120.0 + 10.0 * rank, -20.0, 1.3)
+    images = torch.from_numpy(synth.images(75, NS, H, W)).to(dev)
+    focal, c = torch.tensor(FOCAL), torch.tensor([[W * 0.5, H * 0.5]])
+    poses = torch.from_numpy(src)[None]
+
+    def encode():
+        net.encode(images[None], poses, focal, c=c)
+
+    encode()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        encode()
+    torch.cuda.synchronize()
+    encode_ms = (time.perf_counter() - t0) / 3 * 1e3
+
+    rays = gen_rays(torch.from_numpy(tgt)[None].to(dev), W, H, focal, Z_NEAR, Z_FAR, c=c[0]).reshape(1, -1, 8)
+    n_rays = rays.shape[1]
+    ren = NeRFRenderer(n_coarse=KC, n_fine=KF, n_fine_depth=KFD, depth_std=0.01, white_bkgd=True).eval()
+    par = ren.bind_parallel(net, None, simple_output=True).eval()
+    gathered = torch.empty(world * n_rays, 4, device=dev) if world > 1 else None
+
+    def step():
+        with torch.no_grad():
+            rgb, depth = par(rays)
+        if world > 1:
+            tile = torch.cat([rgb[0], depth[0][:, None]], dim=1)
+            dist.all_gather_into_tensor(gathered, tile)
+        return rgb, depth
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    net.enable_kernel_timing(True)
+    fence()
+    t0 = time.perf_counter()
+    kern_ms = 0.0
+    kern_flops = 0.0
+    launches = 0
+    for _ in range(args.steps):
+        rgb, depth = step()
+        # HIP-event times of this step's MLP launches (recorded on the launch stream inside
+        # libpnyolo; reading them waits for the step, which the next step depends on anyway)
+        fl, ms, nl = net.last_mlp_stats()
+        kern_flops += fl
+        kern_ms += ms
+        launches += nl
+    fence()
+    elapsed = time.perf_counter() - t0
+    net.enable_kernel_timing(False)
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert bool(torch.isfinite(rgb).all()) and bool(torch.isfinite(depth).all())
+
+    total_rays = world * n_rays * args.steps
+    value = total_rays / elapsed
+    achieved = kern_flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else None
+    out = {
+        "metric": METRIC, "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": dict(describe()["config"], n_views=NS, n_coarse=KC, n_fine=KF, n_fine_depth=KFD,
+                       global_rays_per_step=world * n_rays,
+                       parallelism="rays sharded, 1 process/GPU, dp%d, 1 all-gather/frame" % world),
+        "encode_ms": encode_ms,
+        "flop_per_ray": flop_per_ray(),
+        "roofline": {
+            "bound": "mfma", "kernel": "pny_mlp_kernel", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": (achieved / PEAK_F32_MFMA_TFLOPS) if achieved else None,
+            "traffic": None, "launches": launches,
+            "avg_launch_ms": (kern_ms / launches) if launches else None,
+            "flops_per_launch": (kern_flops / launches) if launches else None,
+        },
+    }
+
+    if rank == 0 and args.cpu_rays > 0 and world == 1:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import pnyolo_oracle as orc  # CPU baseline leg: the oracle as the thing timed beside the GPU
+        lat = net.latent(0).cpu().numpy()
+        sc = orc.Scene(synth.mlp_state(71), synth.mlp_state(72), lat, src, focal, c, W, H)
+        nb = args.cpu_rays
+        rs = np.random.RandomState(0)
+        sub = rays[0, torch.from_numpy(rs.choice(n_rays, nb, replace=False)).to(dev)].cpu()
+        draws = (rs.rand(nb, KC).astype(np.float32), rs.rand(nb, KF - KFD).astype(np.float32),
+                 rs.rand(nb, KF - KFD).astype(np.float32), rs.randn(nb, KFD).astype(np.float32))
+        torch.set_num_threads(os.cpu_count() or 1)
+        t0 = time.perf_counter()
+        orc.render(sc, sub, KC, KF, KFD, *draws, chunk=50000)
+        cpu_s = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": nb / cpu_s, "unit": "rays/s", "cores": torch.get_num_threads(),
+                               "kind": "port", "sample": "%d random rays of the same C2 frame, %.1f s" % (nb, cpu_s)}
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

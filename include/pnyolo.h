@@ -1,0 +1,179 @@
+/*
+ * pnyolo.h -- C ABI of libpnyolo.so: the MI355X (gfx950) rendering hot path of
+ * pixelNeRF-YOLO.  Plain pointers and sizes only; no torch types.
+ *
+ * The reference (kofinandi/pixel-nerf-yolo) is pure Python/PyTorch and has no FFI of its own:
+ * the boundary it offers is the Python object protocol between its trainers / eval scripts
+ * and src/render + src/model.  Each entry point below names the reference
+ * interface it stands in for (file:line relative to the reference tree); the Python classes in
+ * pixel-nerf-yolo_amd/ re-create those interfaces on top of this ABI.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative pny_status; it never throws.
+ *     pny_last_error() returns a thread-local message for the last failure.
+ *   - *_dev pointers are device (HIP) pointers owned by the caller and borrowed for the call;
+ *     *_host pointers are host memory.  All floating point data is fp32, row-major.
+ *   - work is enqueued on the caller's stream (hipStream_t passed as void*); the library does
+ *     not synchronise except where a function says so.
+ *   - a pny_model owns packed weights; a pny_scene owns the per-scene state the reference keeps
+ *     in module buffers after encode() (latent, world->cam poses, intrinsics) plus a grow-only
+ *     workspace.  One model / scene per device and per caller thread.
+ */
+#ifndef PNYOLO_H
+#define PNYOLO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PNY_ABI_VERSION 1
+
+typedef enum pny_status {
+    PNY_OK = 0,
+    PNY_ERR_ARG = -1,      /* bad argument / unsupported configuration */
+    PNY_ERR_STATE = -2,    /* call order (e.g. render before weights / latent / cameras) */
+    PNY_ERR_HIP = -3,      /* HIP runtime error (message carries hipGetErrorString) */
+    PNY_ERR_NOGPU = -4     /* no gfx950 device visible */
+} pny_status;
+
+typedef struct pny_model pny_model;
+typedef struct pny_scene pny_scene;
+typedef void* pny_stream; /* hipStream_t */
+
+/* Values the reference reads from conf["model"] (src/model/models.py:21-83,
+ * src/model/resnetfc.py:189-205, src/model/code.py:45-52). */
+typedef struct pny_model_desc {
+    int32_t d_latent;      /* encoder.latent_size: 512 (ResNet34, encoder.py:67) or 1792 (YOLO) */
+    int32_t d_hidden;      /* mlp.d_hidden; this build supports 512 */
+    int32_t d_out;         /* 4, or 7*num_anchors_per_scale = 21 in YOLO mode (models.py:80-83) */
+    int32_t n_blocks;      /* mlp.n_blocks (5) */
+    int32_t combine_layer; /* mlp.combine_layer (3): cross-view mean before this block */
+    int32_t num_freqs;     /* code.num_freqs (6) */
+    float freq_factor;     /* code.freq_factor (1.5) */
+    int32_t yolo;          /* mlp_coarse.yolo: raw outputs, extrinsics used as given, z>=0 culling */
+    int32_t has_fine;      /* mlp_fine.type != empty */
+    int32_t device;        /* HIP device ordinal */
+} pny_model_desc;
+
+int pny_version(void);
+const char* pny_last_error(void);
+
+/* make_model(conf["model"]) -- src/model/__init__.py:4-11, src/model/models.py:16-90 */
+int pny_model_create(pny_model** out, const pny_model_desc* desc);
+void pny_model_destroy(pny_model* m);
+
+/* PixelNeRFNet.load_weights -> load_state_dict, one call per state_dict tensor
+ * (src/model/models.py:320-349).  name is the state_dict key ("mlp_coarse.lin_in.weight",
+ * "mlp_fine.blocks.3.fc_1.bias", "encoder.model.layer2.0.downsample.1.running_var", ...);
+ * unknown keys (code._freqs, layer4.*, fc.*, num_batches_tracked) are accepted and ignored.
+ * data_host: fp32, shape as in the state_dict. */
+int pny_model_load_weights(pny_model* m, const char* name, const float* data_host,
+                           const int64_t* shape, int ndim);
+/* Packs the loaded tensors into the MFMA operand order and uploads them.  Fails with
+ * PNY_ERR_STATE and names the first missing MLP tensor.  Synchronous. */
+int pny_model_finalize(pny_model* m);
+
+int pny_scene_create(pny_scene** out, pny_model* m);
+void pny_scene_destroy(pny_scene* s);
+
+/* Camera half of PixelNeRFNet.encode (src/model/models.py:115-148).
+ * poses_host (ns,4,4): cam->world, inverted here to world->cam [R^T | -R^T t]; in YOLO mode
+ * they are world->cam extrinsics and used as given.  focal_host (nf,2), c_host (nc,2) with
+ * nf, nc in {1, ns}; fy is negated here in non-YOLO mode as the reference does. */
+int pny_scene_set_cameras(pny_scene* s, const float* poses_host, int ns, const float* focal_host, int nf,
+                          const float* c_host, int nc, int width, int height);
+/* Encoder bypass: installs a latent (ns, L, Hl, Wl) NCHW as SpatialEncoder.forward would leave
+ * it in self.latent (src/model/encoder.py:169-172); repacked to NHWC on device. */
+int pny_scene_set_latent(pny_scene* s, const float* latent_dev, int ns, int channels, int hl, int wl,
+                         pny_stream stream);
+/* SpatialEncoder.forward, ResNet-34 trunk, eval-mode batch norm (src/model/encoder.py:139-173).
+ * images_dev (ns,3,H,W) in [-1,1].  Leaves the 512-channel latent (H/2 x W/2) in the scene. */
+int pny_scene_encode(pny_scene* s, const float* images_dev, int ns, int height, int width, pny_stream stream);
+/* Copies the scene latent out as (ns, L, Hl, Wl) NCHW (test / debugging aid). */
+int pny_scene_get_latent(pny_scene* s, float* latent_dev, pny_stream stream);
+int pny_scene_latent_shape(pny_scene* s, int* ns, int* channels, int* hl, int* wl);
+
+/* util.gen_rays (src/util/util.py:240-278, yolo_mode=0: poses cam->world, unit dirs, integer
+ * pixel centres) and util.gen_rays_yolo (src/util/util.py:808-876, yolo_mode=1: poses are
+ * world->cam extrinsics, K^-1 [x+.49,y+.49,1], not normalised).  out_dev (b,H,W,8). */
+int pny_gen_rays(const float* poses_host, int b, int width, int height, const float focal[2],
+                 const float c[2], float z_near, float z_far, int yolo_mode, float* out_dev,
+                 pny_stream stream);
+
+/* PixelNeRFNet.forward for one scene (src/model/models.py:153-318):
+ * xyz_dev, viewdirs_dev (n,3) world space -> out_dev (n,d_out) = [sigmoid rgb, relu sigma]
+ * (YOLO mode: raw).  coarse=0 selects mlp_fine when the model has one. */
+int pny_query(pny_scene* s, const float* xyz_dev, const float* viewdirs_dev, int64_t n, int coarse,
+              float* out_dev, pny_stream stream);
+
+/* NeRFRenderer options (src/render/nerf.py:68-102, from_conf :346-358). */
+typedef struct pny_render_opts {
+    int32_t n_coarse;
+    int32_t n_fine;        /* total fine samples incl. depth samples; 0 = coarse only */
+    int32_t n_fine_depth;
+    float depth_std;
+    int32_t white_bkgd;
+    int32_t lindisp;
+    /* The renderer's random draws (nerf.py:117,141,147,164) are inputs of the path.  Either all
+     * needed pointers are given (parity mode), or they are NULL and an in-kernel Philox stream
+     * keyed by `seed` generates them (perf mode). */
+    const float* u_coarse_dev; /* (n, n_coarse) U[0,1) */
+    const float* u_fine_dev;   /* (n, n_fine-n_fine_depth) U[0,1): inverse-cdf draw */
+    const float* u_fine2_dev;  /* (n, n_fine-n_fine_depth) U[0,1): in-bin jitter */
+    const float* g_depth_dev;  /* (n, n_fine_depth) N(0,1) */
+    uint64_t seed;
+} pny_render_opts;
+
+/* Any output pointer may be NULL. */
+typedef struct pny_render_out {
+    float* rgb_coarse;     /* (n,3) */
+    float* depth_coarse;   /* (n) */
+    float* weights_coarse; /* (n,n_coarse) */
+    float* rgb_fine;       /* (n,3) */
+    float* depth_fine;     /* (n) */
+    float* weights_fine;   /* (n,n_coarse+n_fine) */
+    float* z_coarse;       /* (n,n_coarse) */
+    float* z_fine;         /* (n,n_coarse+n_fine) sorted */
+    float* sample_coarse;  /* (n,n_coarse,4) per-sample [rgb, sigma] from the coarse MLP */
+    float* sample_fine;    /* (n,n_coarse+n_fine,4) */
+} pny_render_out;
+
+/* NeRFRenderer.forward for one scene (src/render/nerf.py:257-309): rays_dev (n,8) =
+ * [origin, dir, near, far]. */
+int pny_render(pny_scene* s, const float* rays_dev, int64_t n, const pny_render_opts* opts,
+               const pny_render_out* out, pny_stream stream);
+
+/* YoloRenderer.forward (src/render/yolo.py:37-114): coarse sampling only, raw (A*7)-vectors,
+ * out_dev (n, A, 7) = [max_k p, sum_k p v / (sum_k p + 1e-5)].  raw_dev (n,K,A*7) optional. */
+int pny_yolo_render(pny_scene* s, const float* rays_dev, int64_t n, int n_coarse, const float* u_coarse_dev,
+                    uint64_t seed, float* out_dev, float* raw_dev, pny_stream stream);
+
+/* Stage entry points (used by the renderer above; exported for stage-wise parity tests). */
+/* NeRFRenderer.sample_coarse, src/render/nerf.py:104-121 */
+int pny_sample_coarse(const float* rays_dev, int64_t n, int n_coarse, int lindisp, const float* u_dev,
+                      uint64_t seed, float* z_dev, pny_stream stream);
+/* NeRFRenderer.composite arithmetic, src/render/nerf.py:184-188,229-250.  sample_dev (n,K,4). */
+int pny_composite(const float* rays_dev, const float* z_dev, const float* sample_dev, int64_t n, int k,
+                  int white_bkgd, float* weights_dev, float* rgb_dev, float* depth_dev, pny_stream stream);
+/* sample_fine + sample_fine_depth + cat + sort, src/render/nerf.py:126-167,291-301.
+ * z_out_dev (n, n_coarse+n_fine) ascending. */
+int pny_sample_fine(const float* rays_dev, const float* z_coarse_dev, const float* weights_dev,
+                    const float* depth_dev, int64_t n, int n_coarse, int n_fine, int n_fine_depth,
+                    float depth_std, int lindisp, const float* u_dev, const float* u2_dev,
+                    const float* g_dev, uint64_t seed, float* z_out_dev, pny_stream stream);
+/* YoloRenderer aggregation, src/render/yolo.py:96-114.  raw_dev (n,K,A*7) -> out_dev (n,A,7). */
+int pny_yolo_aggregate(const float* raw_dev, int64_t n, int k, int n_anchors, float* out_dev,
+                       pny_stream stream);
+
+/* Introspection for bench.py: name and algorithmic FLOPs (2/MAC, MLP GEMMs only) of the last
+ * pny_render / pny_query on this scene, and the HIP-event time of its MLP kernel launches. */
+int pny_scene_last_mlp_stats(pny_scene* s, double* flops, double* kernel_ms, int* launches);
+int pny_scene_enable_timing(pny_scene* s, int enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PNYOLO_H */

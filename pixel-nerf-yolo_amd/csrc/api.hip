@@ -1,0 +1,670 @@
+// C ABI of libpnyolo.so (include/pnyolo.h): handles, weight packing, per-scene state and the
+// launch sequences of a query / render call.  Host-side C++; all arithmetic of the hot path is
+// in the kernels (mlp.hip, render_kernels.hip, encoder.hip).
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "pny_common.h"
+#include "encoder.h"
+
+namespace pny {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+int hip_fail(hipError_t e, const char* what) {
+    g_err = std::string("HIP error: ") + hipGetErrorString(e) + " in " + what;
+    return PNY_ERR_HIP;
+}
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int reserve(size_t need) {
+        if (need <= bytes) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        hipError_t e = hipMalloc(&p, need);
+        if (e != hipSuccess) return hip_fail(e, "hipMalloc(workspace)");
+        bytes = need;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    float* f() const { return reinterpret_cast<float*>(p); }
+};
+
+}  // namespace pny
+
+using namespace pny;
+
+struct pny_model {
+    pny_model_desc desc;
+    std::map<std::string, HostTensor> host;  // state_dict tensors as loaded
+    bool finalized = false;
+    DevBuf packed;                            // all MLP weights, one allocation
+    MlpWeights coarse{}, fine{};
+    EncoderWeights enc;                       // folded conv+bn (encoder.h)
+    bool has_encoder = false;
+};
+
+struct pny_scene {
+    pny_model* m = nullptr;
+    int ns = 0, L = 0, hl = 0, wl = 0;  // latent
+    int width = 0, height = 0;
+    bool have_cams = false, have_latent = false;
+    int cam_ns = 0;
+    DevBuf cams, latent, work, scratch, enc_work;
+    // timing of the MLP launches of the last call
+    bool timing = false;
+    std::vector<hipEvent_t> ev;
+    int ev_used = 0;
+    double last_flops = 0.0;
+    int last_launches = 0;
+};
+
+// ---------------------------------------------------------------------------------- packing
+// A-operand order of v_mfma_f32_32x32x2_f32 for H^T = W X^T (see mlp.hip): for n-tile nt (32
+// output features), k-iteration j (8 inputs), lane l, component r:
+//     Wp[((nt*J + j)*64 + l)*4 + r] = W[32 nt + (l & 31)][8 j + 4 (l >> 5) + r]   (0 beyond K)
+static void pack_layer(const float* W, int n_out, int k_in, int k_pad, std::vector<float>& dst) {
+    const int J = k_pad / 8, NT = n_out / 32;
+    const size_t base = dst.size();
+    dst.resize(base + (size_t)NT * J * 64 * 4);
+    float* o = dst.data() + base;
+    for (int nt = 0; nt < NT; ++nt)
+        for (int j = 0; j < J; ++j)
+            for (int l = 0; l < 64; ++l)
+                for (int r = 0; r < 4; ++r) {
+                    const int n = 32 * nt + (l & 31), k = 8 * j + 4 * (l >> 5) + r;
+                    *o++ = (k < k_in) ? W[(size_t)n * k_in + k] : 0.0f;
+                }
+}
+
+static const HostTensor* find(const pny_model* m, const std::string& name) {
+    auto it = m->host.find(name);
+    return it == m->host.end() ? nullptr : &it->second;
+}
+
+static int need(const pny_model* m, const std::string& name, std::vector<int64_t> shape, const HostTensor** out) {
+    const HostTensor* t = find(m, name);
+    if (!t) return fail(PNY_ERR_STATE, "missing weight tensor '" + name + "'");
+    if (t->shape != shape) return fail(PNY_ERR_ARG, "weight tensor '" + name + "' has an unexpected shape");
+    *out = t;
+    return 0;
+}
+
+struct PackPlan {
+    std::vector<float> blob;
+    std::vector<std::pair<const float**, size_t>> fix;  // pointer slot -> offset in blob
+    size_t add_plain(const std::vector<float>& v) {
+        // keep every sub-buffer 64-byte aligned
+        while (blob.size() % 16) blob.push_back(0.f);
+        const size_t off = blob.size();
+        blob.insert(blob.end(), v.begin(), v.end());
+        return off;
+    }
+};
+
+static int pack_mlp(pny_model* m, const std::string& pre, MlpWeights& w, PackPlan& plan) {
+    const pny_model_desc& d = m->desc;
+    const int d_in = 3 + 6 * d.num_freqs + 3;
+    const int nvb = d.combine_layer < d.n_blocks ? d.combine_layer : d.n_blocks;
+    const HostTensor* t = nullptr;
+    int rc;
+    auto packed = [&](const std::string& name, int k_in, int k_pad, const float** slot) -> int {
+        if ((rc = need(m, name, {HID, k_in}, &t))) return rc;
+        while (plan.blob.size() % 16) plan.blob.push_back(0.f);
+        const size_t off = plan.blob.size();
+        pack_layer(t->data.data(), HID, k_in, k_pad, plan.blob);
+        plan.fix.push_back({slot, off});
+        return 0;
+    };
+    auto plain = [&](const std::string& name, std::vector<int64_t> shape, const float** slot) -> int {
+        if ((rc = need(m, name, shape, &t))) return rc;
+        plan.fix.push_back({slot, plan.add_plain(t->data)});
+        return 0;
+    };
+    if ((rc = packed(pre + "lin_in.weight", d_in, D_IN_PAD, &w.w_in))) return rc;
+    if ((rc = plain(pre + "lin_in.bias", {HID}, &w.b_in))) return rc;
+    for (int b = 0; b < nvb; ++b) {
+        const std::string p = pre + "lin_z." + std::to_string(b);
+        if ((rc = packed(p + ".weight", d.d_latent, d.d_latent, &w.w_z[b]))) return rc;
+        if ((rc = plain(p + ".bias", {HID}, &w.b_z[b]))) return rc;
+    }
+    for (int b = 0; b < d.n_blocks; ++b) {
+        const std::string p = pre + "blocks." + std::to_string(b);
+        if ((rc = packed(p + ".fc_0.weight", HID, HID, &w.w_fc0[b]))) return rc;
+        if ((rc = plain(p + ".fc_0.bias", {HID}, &w.b_fc0[b]))) return rc;
+        if ((rc = packed(p + ".fc_1.weight", HID, HID, &w.w_fc1[b]))) return rc;
+        if ((rc = plain(p + ".fc_1.bias", {HID}, &w.b_fc1[b]))) return rc;
+    }
+    if ((rc = plain(pre + "lin_out.weight", {d.d_out, HID}, &w.w_out))) return rc;
+    if ((rc = plain(pre + "lin_out.bias", {d.d_out}, &w.b_out))) return rc;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------- C ABI
+extern "C" {
+
+int pny_version(void) { return PNY_ABI_VERSION; }
+const char* pny_last_error(void) { return g_err.c_str(); }
+
+int pny_model_create(pny_model** out, const pny_model_desc* desc) {
+    if (!out || !desc) return fail(PNY_ERR_ARG, "pny_model_create: null argument");
+    if (desc->d_hidden != HID) return fail(PNY_ERR_ARG, "pny_model_create: d_hidden must be 512");
+    if (desc->n_blocks < 1 || desc->n_blocks > MAX_BLOCKS) return fail(PNY_ERR_ARG, "pny_model_create: n_blocks out of range [1,8]");
+    if (desc->combine_layer < 0) return fail(PNY_ERR_ARG, "pny_model_create: combine_layer < 0");
+    if (desc->d_latent < 32 || desc->d_latent % 32) return fail(PNY_ERR_ARG, "pny_model_create: d_latent must be a positive multiple of 32");
+    if (desc->d_out < 1 || desc->d_out > 64) return fail(PNY_ERR_ARG, "pny_model_create: d_out out of range [1,64]");
+    if (3 + 6 * desc->num_freqs + 3 > D_IN_PAD || desc->num_freqs < 0) return fail(PNY_ERR_ARG, "pny_model_create: num_freqs too large (d_in must be <= 48)");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(PNY_ERR_NOGPU, "pny_model_create: no HIP device visible (this library has no CPU path)");
+    if (desc->device < 0 || desc->device >= count) return fail(PNY_ERR_ARG, "pny_model_create: device ordinal out of range");
+    PNY_HIP(hipSetDevice(desc->device));
+    pny_model* m = new pny_model();
+    m->desc = *desc;
+    *out = m;
+    return PNY_OK;
+}
+
+void pny_model_destroy(pny_model* m) {
+    if (!m) return;
+    m->packed.release();
+    m->enc.release();
+    delete m;
+}
+
+int pny_model_load_weights(pny_model* m, const char* name, const float* data_host, const int64_t* shape, int ndim) {
+    if (!m || !name || (!data_host && ndim > 0) || ndim < 0 || ndim > 4) return fail(PNY_ERR_ARG, "pny_model_load_weights: bad argument");
+    HostTensor t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) {
+        if (shape[i] < 0) return fail(PNY_ERR_ARG, "pny_model_load_weights: negative dimension");
+        t.shape.push_back(shape[i]);
+        n *= (size_t)shape[i];
+    }
+    t.data.assign(data_host, data_host + n);
+    m->host[name] = std::move(t);
+    m->finalized = false;
+    return PNY_OK;
+}
+
+int pny_model_finalize(pny_model* m) {
+    if (!m) return fail(PNY_ERR_ARG, "pny_model_finalize: null model");
+    PNY_HIP(hipSetDevice(m->desc.device));
+    PackPlan plan;
+    int rc;
+    if ((rc = pack_mlp(m, "mlp_coarse.", m->coarse, plan))) return rc;
+    if (m->desc.has_fine && (rc = pack_mlp(m, "mlp_fine.", m->fine, plan))) return rc;
+    if ((rc = m->packed.reserve(plan.blob.size() * sizeof(float)))) return rc;
+    PNY_HIP(hipMemcpy(m->packed.p, plan.blob.data(), plan.blob.size() * sizeof(float), hipMemcpyHostToDevice));
+    for (auto& f : plan.fix) *f.first = m->packed.f() + f.second;
+    if (!m->desc.has_fine) m->fine = m->coarse;
+    // encoder weights are optional (a scene may be fed through pny_scene_set_latent instead)
+    m->has_encoder = false;
+    if (find(m, "encoder.model.conv1.weight")) {
+        auto get = [&](const std::string& name, const float** data, std::vector<int64_t>* shape) -> bool {
+            const HostTensor* t = find(m, name);
+            if (!t) return false;
+            *data = t->data.data();
+            *shape = t->shape;
+            return true;
+        };
+        std::string err;
+        if (!m->enc.build(get, "encoder.model.", &err)) return fail(PNY_ERR_STATE, "encoder weights: " + err);
+        m->has_encoder = true;
+    }
+    m->finalized = true;
+    return PNY_OK;
+}
+
+int pny_scene_create(pny_scene** out, pny_model* m) {
+    if (!out || !m) return fail(PNY_ERR_ARG, "pny_scene_create: null argument");
+    pny_scene* s = new pny_scene();
+    s->m = m;
+    *out = s;
+    return PNY_OK;
+}
+
+void pny_scene_destroy(pny_scene* s) {
+    if (!s) return;
+    s->cams.release();
+    s->latent.release();
+    s->work.release();
+    s->scratch.release();
+    s->enc_work.release();
+    for (auto e : s->ev) (void)hipEventDestroy(e);
+    delete s;
+}
+
+int pny_scene_set_cameras(pny_scene* s, const float* poses, int ns, const float* focal, int nf, const float* c, int nc,
+                          int width, int height) {
+    if (!s || !poses || !focal || !c) return fail(PNY_ERR_ARG, "pny_scene_set_cameras: null argument");
+    if (ns < 1 || ns > MAX_VIEWS) return fail(PNY_ERR_ARG, "pny_scene_set_cameras: ns out of range [1,16]");
+    if ((nf != 1 && nf != ns) || (nc != 1 && nc != ns)) return fail(PNY_ERR_ARG, "pny_scene_set_cameras: focal / c count must be 1 or ns");
+    if (width < 1 || height < 1) return fail(PNY_ERR_ARG, "pny_scene_set_cameras: bad image size");
+    PNY_HIP(hipSetDevice(s->m->desc.device));
+    std::vector<Cam> cams(ns);
+    for (int v = 0; v < ns; ++v) {
+        const float* P = poses + 16 * v;
+        Cam& cm = cams[v];
+        if (!s->m->desc.yolo) {
+            // reference models.py:116-118: rot = R^T, trans = -(R^T t) via bmm (fp32)
+            for (int i = 0; i < 3; ++i) {
+                for (int j = 0; j < 3; ++j) cm.w2c[4 * i + j] = P[4 * j + i];
+                float acc = 0.f;
+                for (int j = 0; j < 3; ++j) acc += P[4 * j + i] * P[4 * j + 3];
+                cm.w2c[4 * i + 3] = -acc;
+            }
+        } else {
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 4; ++j) cm.w2c[4 * i + j] = P[4 * i + j];
+        }
+        const float* f = focal + 2 * (nf == 1 ? 0 : v);
+        const float* cc = c + 2 * (nc == 1 ? 0 : v);
+        cm.fx = f[0];
+        cm.fy = s->m->desc.yolo ? f[1] : -f[1];  // models.py:136-137
+        cm.cx = cc[0];
+        cm.cy = cc[1];
+    }
+    int rc;
+    if ((rc = s->cams.reserve(sizeof(Cam) * MAX_VIEWS))) return rc;
+    PNY_HIP(hipMemcpy(s->cams.p, cams.data(), sizeof(Cam) * ns, hipMemcpyHostToDevice));
+    s->cam_ns = ns;
+    s->width = width;
+    s->height = height;
+    s->have_cams = true;
+    return PNY_OK;
+}
+
+int pny_scene_set_latent(pny_scene* s, const float* latent_dev, int ns, int channels, int hl, int wl, pny_stream stream) {
+    if (!s || !latent_dev) return fail(PNY_ERR_ARG, "pny_scene_set_latent: null argument");
+    if (channels != s->m->desc.d_latent) return fail(PNY_ERR_ARG, "pny_scene_set_latent: channel count != model d_latent");
+    if (ns < 1 || ns > MAX_VIEWS || hl < 1 || wl < 1) return fail(PNY_ERR_ARG, "pny_scene_set_latent: bad shape");
+    if ((long long)hl * wl * channels >= (1ll << 31)) return fail(PNY_ERR_ARG, "pny_scene_set_latent: latent too large for 32-bit tap offsets");
+    PNY_HIP(hipSetDevice(s->m->desc.device));
+    int rc;
+    if ((rc = s->latent.reserve((size_t)ns * channels * hl * wl * sizeof(float)))) return rc;
+    launch_nchw_to_nhwc(latent_dev, s->latent.f(), ns, channels, hl * wl, (hipStream_t)stream);
+    PNY_HIP(hipGetLastError());
+    s->ns = ns;
+    s->L = channels;
+    s->hl = hl;
+    s->wl = wl;
+    s->have_latent = true;
+    return PNY_OK;
+}
+
+int pny_scene_encode(pny_scene* s, const float* images_dev, int ns, int height, int width, pny_stream stream) {
+    if (!s || !images_dev) return fail(PNY_ERR_ARG, "pny_scene_encode: null argument");
+    if (!s->m->finalized) return fail(PNY_ERR_STATE, "pny_scene_encode: call pny_model_finalize first");
+    if (!s->m->has_encoder) return fail(PNY_ERR_STATE, "pny_scene_encode: no encoder.model.* weights were loaded");
+    if (s->m->desc.d_latent != 512) return fail(PNY_ERR_ARG, "pny_scene_encode: ResNet-34 trunk yields 512 channels; model d_latent differs");
+    if (ns < 1 || ns > MAX_VIEWS || height < 32 || width < 32) return fail(PNY_ERR_ARG, "pny_scene_encode: bad shape");
+    PNY_HIP(hipSetDevice(s->m->desc.device));
+    int hl = 0, wl = 0;
+    encoder_latent_size(height, width, &hl, &wl);
+    int rc;
+    if ((rc = s->latent.reserve((size_t)ns * 512 * hl * wl * sizeof(float)))) return rc;
+    if ((rc = s->enc_work.reserve(encoder_workspace_bytes(ns, height, width)))) return rc;
+    std::string err;
+    if (!encoder_forward(s->m->enc, images_dev, ns, height, width, s->enc_work.f(), s->latent.f(), (hipStream_t)stream, &err))
+        return fail(PNY_ERR_HIP, "pny_scene_encode: " + err);
+    s->ns = ns;
+    s->L = 512;
+    s->hl = hl;
+    s->wl = wl;
+    s->have_latent = true;
+    return PNY_OK;
+}
+
+int pny_scene_latent_shape(pny_scene* s, int* ns, int* channels, int* hl, int* wl) {
+    if (!s || !s->have_latent) return fail(PNY_ERR_STATE, "pny_scene_latent_shape: no latent");
+    if (ns) *ns = s->ns;
+    if (channels) *channels = s->L;
+    if (hl) *hl = s->hl;
+    if (wl) *wl = s->wl;
+    return PNY_OK;
+}
+
+int pny_scene_get_latent(pny_scene* s, float* latent_dev, pny_stream stream) {
+    if (!s || !latent_dev) return fail(PNY_ERR_ARG, "pny_scene_get_latent: null argument");
+    if (!s->have_latent) return fail(PNY_ERR_STATE, "pny_scene_get_latent: no latent");
+    PNY_HIP(hipSetDevice(s->m->desc.device));
+    launch_nhwc_to_nchw(s->latent.f(), latent_dev, s->ns, s->L, s->hl * s->wl, (hipStream_t)stream);
+    PNY_HIP(hipGetLastError());
+    return PNY_OK;
+}
+
+// 3x3 / 4x4 inverses on the host in double precision (reference uses torch.inverse on fp32).
+static bool invert4(const float* m, double* inv) {
+    double a[4][8];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            a[i][j] = m[4 * i + j];
+            a[i][4 + j] = (i == j) ? 1.0 : 0.0;
+        }
+    for (int c = 0; c < 4; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < 4; ++r)
+            if (std::fabs(a[r][c]) > std::fabs(a[piv][c])) piv = r;
+        if (std::fabs(a[piv][c]) < 1e-30) return false;
+        if (piv != c)
+            for (int j = 0; j < 8; ++j) std::swap(a[piv][j], a[c][j]);
+        const double d = a[c][c];
+        for (int j = 0; j < 8; ++j) a[c][j] /= d;
+        for (int r = 0; r < 4; ++r)
+            if (r != c) {
+                const double f = a[r][c];
+                for (int j = 0; j < 8; ++j) a[r][j] -= f * a[c][j];
+            }
+    }
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) inv[4 * i + j] = a[i][4 + j];
+    return true;
+}
+
+int pny_gen_rays(const float* poses_host, int b, int width, int height, const float focal[2], const float c[2],
+                 float z_near, float z_far, int yolo_mode, float* out_dev, pny_stream stream) {
+    if (!poses_host || !focal || !c || !out_dev) return fail(PNY_ERR_ARG, "pny_gen_rays: null argument");
+    if (b < 0 || width < 1 || height < 1) return fail(PNY_ERR_ARG, "pny_gen_rays: bad shape");
+    if (b == 0) return PNY_OK;
+    std::vector<float> cam((size_t)b * 16);
+    for (int i = 0; i < b; ++i) {
+        const float* P = poses_host + 16 * i;
+        float* o = cam.data() + 16 * i;
+        if (!yolo_mode) {
+            for (int r = 0; r < 3; ++r) {
+                for (int q = 0; q < 3; ++q) o[3 * r + q] = P[4 * r + q];
+                o[9 + r] = P[4 * r + 3];
+            }
+            o[12] = focal[0];
+            o[13] = focal[1];
+            o[14] = c[0];
+            o[15] = c[1];
+        } else {
+            double inv[16];
+            if (!invert4(P, inv)) return fail(PNY_ERR_ARG, "pny_gen_rays: singular extrinsic matrix");
+            for (int r = 0; r < 3; ++r) {
+                for (int q = 0; q < 3; ++q) o[3 * r + q] = (float)inv[4 * r + q];
+                o[9 + r] = (float)inv[4 * r + 3];
+            }
+            if (focal[0] == 0.f || focal[1] == 0.f) return fail(PNY_ERR_ARG, "pny_gen_rays: zero focal length");
+            o[12] = (float)(1.0 / focal[0]);
+            o[13] = (float)(1.0 / focal[1]);
+            o[14] = (float)(-(double)c[0] / focal[0]);
+            o[15] = (float)(-(double)c[1] / focal[1]);
+        }
+    }
+    // small per-call parameter block: staged through a stream-ordered device allocation
+    float* dcam = nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    PNY_HIP(hipMalloc((void**)&dcam, cam.size() * sizeof(float)));
+    hipError_t e = hipMemcpyAsync(dcam, cam.data(), cam.size() * sizeof(float), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        launch_gen_rays(dcam, b, width, height, z_near, z_far, yolo_mode, out_dev, st);
+        e = hipGetLastError();
+    }
+    hipError_t e2 = hipStreamSynchronize(st);  // cam is a host temporary and dcam is freed below
+    (void)hipFree(dcam);
+    if (e != hipSuccess) return hip_fail(e, "pny_gen_rays launch");
+    if (e2 != hipSuccess) return hip_fail(e2, "pny_gen_rays sync");
+    return PNY_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------- MLP launch
+static int check_ready(pny_scene* s, const char* who) {
+    if (!s) return fail(PNY_ERR_ARG, std::string(who) + ": null scene");
+    if (!s->m->finalized) return fail(PNY_ERR_STATE, std::string(who) + ": weights not finalized (pny_model_finalize)");
+    if (!s->have_latent) return fail(PNY_ERR_STATE, std::string(who) + ": scene has no latent (pny_scene_encode / pny_scene_set_latent)");
+    if (!s->have_cams) return fail(PNY_ERR_STATE, std::string(who) + ": scene has no cameras (pny_scene_set_cameras)");
+    if (s->cam_ns != s->ns) return fail(PNY_ERR_STATE, std::string(who) + ": camera count != latent view count");
+    if (s->ns > 1 && s->m->desc.combine_layer >= s->m->desc.n_blocks)
+        return fail(PNY_ERR_ARG, std::string(who) + ": multi-view scene needs combine_layer < n_blocks");
+    return 0;
+}
+
+static double mlp_flops_per_point(const pny_model_desc& d, int ns) {
+    const int d_in = 3 + 6 * d.num_freqs + 3;
+    const int nvb = d.combine_layer < d.n_blocks ? d.combine_layer : d.n_blocks;
+    const double per_view = (double)d_in * HID + (double)nvb * d.d_latent * HID + 2.0 * nvb * HID * HID;
+    const double post = 2.0 * (d.n_blocks - nvb) * HID * HID + (double)HID * d.d_out;
+    return 2.0 * (ns * per_view + post);
+}
+
+static int run_mlp(pny_scene* s, int mode, const float* xyz, const float* dirs, const float* rays, const float* z,
+                   int K, long long n_points, int coarse, float* out, hipStream_t st) {
+    if (n_points == 0) return 0;
+    const pny_model_desc& d = s->m->desc;
+    MlpArgs a;
+    memset(&a, 0, sizeof(a));
+    a.w = (coarse || !d.has_fine) ? s->m->coarse : s->m->fine;
+    a.latent = s->latent.f();
+    a.cams = reinterpret_cast<const Cam*>(s->cams.p);
+    a.xyz = xyz;
+    a.dirs = dirs;
+    a.rays = rays;
+    a.z = z;
+    a.out = out;
+    a.n_points = n_points;
+    a.K = K;
+    a.mode = mode;
+    a.NS = s->ns;
+    a.L = s->L;
+    a.Hl = s->hl;
+    a.Wl = s->wl;
+    a.n_blocks = d.n_blocks;
+    a.combine_layer = d.combine_layer;
+    a.d_out = d.d_out;
+    a.yolo = d.yolo;
+    a.num_freqs = d.num_freqs;
+    a.freq_factor = d.freq_factor;
+    // latent_scaling / image_size in fp32 (reference encoder.py:97,170-172)
+    const float lsx = (float)s->wl / ((float)s->wl - 1.0f) * 2.0f;
+    const float lsy = (float)s->hl / ((float)s->hl - 1.0f) * 2.0f;
+    a.sx = lsx / (float)s->width;
+    a.sy = lsy / (float)s->height;
+    const long long tiles = (n_points + TM - 1) / TM;
+    if (tiles > 0x7fffffffll) return fail(PNY_ERR_ARG, "too many points for one launch");
+    a.n_tiles = (int)tiles;
+    int grid = mlp_max_grid();
+    if (tiles < grid) grid = (int)tiles;
+    int rc;
+    if ((rc = s->scratch.reserve((size_t)mlp_max_grid() * TM * HID * sizeof(float)))) return rc;
+    a.scratch = s->scratch.f();
+    if (s->timing) {
+        while ((int)s->ev.size() < s->ev_used + 2) {
+            hipEvent_t e;
+            PNY_HIP(hipEventCreate(&e));
+            s->ev.push_back(e);
+        }
+        PNY_HIP(hipEventRecord(s->ev[s->ev_used], st));
+    }
+    launch_mlp(a, grid, st);
+    PNY_HIP(hipGetLastError());
+    if (s->timing) {
+        PNY_HIP(hipEventRecord(s->ev[s->ev_used + 1], st));
+        s->ev_used += 2;
+    }
+    s->last_flops += mlp_flops_per_point(d, s->ns) * (double)n_points;
+    s->last_launches += 1;
+    return 0;
+}
+
+static void begin_call(pny_scene* s) {
+    s->ev_used = 0;
+    s->last_flops = 0.0;
+    s->last_launches = 0;
+}
+
+extern "C" {
+
+int pny_query(pny_scene* s, const float* xyz_dev, const float* viewdirs_dev, int64_t n, int coarse, float* out_dev,
+              pny_stream stream) {
+    int rc;
+    if ((rc = check_ready(s, "pny_query"))) return rc;
+    if (n < 0 || (n > 0 && (!xyz_dev || !viewdirs_dev || !out_dev))) return fail(PNY_ERR_ARG, "pny_query: bad argument");
+    PNY_HIP(hipSetDevice(s->m->desc.device));
+    begin_call(s);
+    return run_mlp(s, 0, xyz_dev, viewdirs_dev, nullptr, nullptr, 1, n, coarse, out_dev, (hipStream_t)stream);
+}
+
+int pny_sample_coarse(const float* rays_dev, int64_t n, int n_coarse, int lindisp, const float* u_dev, uint64_t seed,
+                      float* z_dev, pny_stream stream) {
+    if (n < 0 || n_coarse < 1 || (n > 0 && (!rays_dev || !z_dev))) return fail(PNY_ERR_ARG, "pny_sample_coarse: bad argument");
+    launch_sample_coarse(rays_dev, n, n_coarse, lindisp, u_dev, seed, z_dev, (hipStream_t)stream);
+    PNY_HIP(hipGetLastError());
+    return PNY_OK;
+}
+
+int pny_composite(const float* rays_dev, const float* z_dev, const float* sample_dev, int64_t n, int k, int white_bkgd,
+                  float* weights_dev, float* rgb_dev, float* depth_dev, pny_stream stream) {
+    if (n < 0 || k < 1 || (n > 0 && (!rays_dev || !z_dev || !sample_dev))) return fail(PNY_ERR_ARG, "pny_composite: bad argument");
+    launch_composite(rays_dev, z_dev, sample_dev, n, k, white_bkgd, weights_dev, rgb_dev, depth_dev, (hipStream_t)stream);
+    PNY_HIP(hipGetLastError());
+    return PNY_OK;
+}
+
+int pny_sample_fine(const float* rays_dev, const float* z_coarse_dev, const float* weights_dev, const float* depth_dev,
+                    int64_t n, int n_coarse, int n_fine, int n_fine_depth, float depth_std, int lindisp,
+                    const float* u_dev, const float* u2_dev, const float* g_dev, uint64_t seed, float* z_out_dev,
+                    pny_stream stream) {
+    if (n < 0 || n_coarse < 1 || n_fine < 0 || n_fine_depth < 0 || n_fine_depth > n_fine)
+        return fail(PNY_ERR_ARG, "pny_sample_fine: bad sample counts");
+    if (n > 0 && (!rays_dev || !z_coarse_dev || !weights_dev || !z_out_dev || (n_fine_depth > 0 && !depth_dev)))
+        return fail(PNY_ERR_ARG, "pny_sample_fine: null argument");
+    if ((size_t)(2 * n_coarse + 1 + n_fine) * 64 * sizeof(float) > 160 * 1024)
+        return fail(PNY_ERR_ARG, "pny_sample_fine: n_coarse + n_fine too large for the LDS-resident sort");
+    launch_sample_fine(rays_dev, z_coarse_dev, weights_dev, depth_dev, n, n_coarse, n_fine, n_fine_depth, depth_std,
+                       lindisp, u_dev, u2_dev, g_dev, seed, z_out_dev, (hipStream_t)stream);
+    PNY_HIP(hipGetLastError());
+    return PNY_OK;
+}
+
+int pny_yolo_aggregate(const float* raw_dev, int64_t n, int k, int n_anchors, float* out_dev, pny_stream stream) {
+    if (n < 0 || k < 1 || n_anchors < 1 || (n > 0 && (!raw_dev || !out_dev))) return fail(PNY_ERR_ARG, "pny_yolo_aggregate: bad argument");
+    launch_yolo_aggregate(raw_dev, n, k, n_anchors, out_dev, (hipStream_t)stream);
+    PNY_HIP(hipGetLastError());
+    return PNY_OK;
+}
+
+int pny_render(pny_scene* s, const float* rays_dev, int64_t n, const pny_render_opts* o, const pny_render_out* out,
+               pny_stream stream) {
+    int rc;
+    if ((rc = check_ready(s, "pny_render"))) return rc;
+    if (!o || !out || n < 0 || (n > 0 && !rays_dev)) return fail(PNY_ERR_ARG, "pny_render: bad argument");
+    if (s->m->desc.yolo || s->m->desc.d_out != 4) return fail(PNY_ERR_ARG, "pny_render: model is in YOLO mode (use pny_yolo_render)");
+    if (o->n_coarse < 1 || o->n_fine < 0 || o->n_fine_depth < 0 || o->n_fine_depth > o->n_fine)
+        return fail(PNY_ERR_ARG, "pny_render: bad sample counts");
+    const int kimp = o->n_fine - o->n_fine_depth;
+    const bool any_u = o->u_coarse_dev || o->u_fine_dev || o->u_fine2_dev || o->g_depth_dev;
+    if (any_u) {
+        if (!o->u_coarse_dev || (kimp > 0 && (!o->u_fine_dev || !o->u_fine2_dev)) || (o->n_fine_depth > 0 && !o->g_depth_dev))
+            return fail(PNY_ERR_ARG, "pny_render: explicit random draws must be given for every stage or for none");
+    }
+    if (n == 0) return PNY_OK;
+    PNY_HIP(hipSetDevice(s->m->desc.device));
+    hipStream_t st = (hipStream_t)stream;
+    begin_call(s);
+    const int kc = o->n_coarse, kt = o->n_coarse + o->n_fine;
+    // workspace carve (floats): z_c, samp_c, w_c, rgb_c(3)+depth_c, z_f, samp_f
+    size_t off = 0;
+    auto carve = [&](size_t nfl) {
+        size_t r = off;
+        off += (nfl + 63) & ~(size_t)63;
+        return r;
+    };
+    const size_t o_zc = carve((size_t)n * kc), o_sc = carve((size_t)n * kc * 4), o_wc = carve((size_t)n * kc);
+    const size_t o_dc = carve((size_t)n), o_rc = carve((size_t)n * 3);
+    const size_t o_zf = carve((size_t)n * kt), o_sf = carve((size_t)n * kt * 4);
+    if ((rc = s->work.reserve(off * sizeof(float)))) return rc;
+    float* W = s->work.f();
+    float* zc = out->z_coarse ? out->z_coarse : W + o_zc;
+    float* sc = out->sample_coarse ? out->sample_coarse : W + o_sc;
+    float* wc = out->weights_coarse ? out->weights_coarse : W + o_wc;
+    float* dc = out->depth_coarse ? out->depth_coarse : W + o_dc;
+    float* rgbc = out->rgb_coarse ? out->rgb_coarse : W + o_rc;
+
+    launch_sample_coarse(rays_dev, n, kc, o->lindisp, o->u_coarse_dev, o->seed, zc, st);
+    if ((rc = run_mlp(s, 1, nullptr, nullptr, rays_dev, zc, kc, (long long)n * kc, 1, sc, st))) return rc;
+    launch_composite(rays_dev, zc, sc, n, kc, o->white_bkgd, wc, rgbc, dc, st);
+    if (o->n_fine > 0) {
+        float* zf = out->z_fine ? out->z_fine : W + o_zf;
+        float* sf = out->sample_fine ? out->sample_fine : W + o_sf;
+        if ((size_t)(2 * kc + 1 + o->n_fine) * 64 * sizeof(float) > 160 * 1024)
+            return fail(PNY_ERR_ARG, "pny_render: n_coarse + n_fine too large for the LDS-resident sort");
+        launch_sample_fine(rays_dev, zc, wc, dc, n, kc, o->n_fine, o->n_fine_depth, o->depth_std, o->lindisp,
+                           o->u_fine_dev, o->u_fine2_dev, o->g_depth_dev, o->seed, zf, st);
+        if ((rc = run_mlp(s, 1, nullptr, nullptr, rays_dev, zf, kt, (long long)n * kt, 0, sf, st))) return rc;
+        launch_composite(rays_dev, zf, sf, n, kt, o->white_bkgd, out->weights_fine, out->rgb_fine, out->depth_fine, st);
+    }
+    PNY_HIP(hipGetLastError());
+    return PNY_OK;
+}
+
+int pny_yolo_render(pny_scene* s, const float* rays_dev, int64_t n, int n_coarse, const float* u_coarse_dev,
+                    uint64_t seed, float* out_dev, float* raw_dev, pny_stream stream) {
+    int rc;
+    if ((rc = check_ready(s, "pny_yolo_render"))) return rc;
+    const pny_model_desc& d = s->m->desc;
+    if (!d.yolo || d.d_out % 7) return fail(PNY_ERR_ARG, "pny_yolo_render: model is not in YOLO mode");
+    if (n < 0 || n_coarse < 1 || (n > 0 && (!rays_dev || !out_dev))) return fail(PNY_ERR_ARG, "pny_yolo_render: bad argument");
+    if (n == 0) return PNY_OK;
+    PNY_HIP(hipSetDevice(d.device));
+    hipStream_t st = (hipStream_t)stream;
+    begin_call(s);
+    const size_t nz = ((size_t)n * n_coarse + 63) & ~(size_t)63;
+    if ((rc = s->work.reserve((nz + (size_t)n * n_coarse * d.d_out) * sizeof(float)))) return rc;
+    float* z = s->work.f();
+    float* raw = raw_dev ? raw_dev : s->work.f() + nz;
+    launch_sample_coarse(rays_dev, n, n_coarse, 0, u_coarse_dev, seed, z, st);
+    if ((rc = run_mlp(s, 1, nullptr, nullptr, rays_dev, z, n_coarse, (long long)n * n_coarse, 1, raw, st))) return rc;
+    launch_yolo_aggregate(raw, n, n_coarse, d.d_out / 7, out_dev, st);
+    PNY_HIP(hipGetLastError());
+    return PNY_OK;
+}
+
+int pny_scene_enable_timing(pny_scene* s, int enable) {
+    if (!s) return fail(PNY_ERR_ARG, "pny_scene_enable_timing: null scene");
+    s->timing = enable != 0;
+    return PNY_OK;
+}
+
+int pny_scene_last_mlp_stats(pny_scene* s, double* flops, double* kernel_ms, int* launches) {
+    if (!s) return fail(PNY_ERR_ARG, "pny_scene_last_mlp_stats: null scene");
+    if (flops) *flops = s->last_flops;
+    if (launches) *launches = s->last_launches;
+    if (kernel_ms) {
+        double tot = 0.0;
+        for (int i = 0; i + 1 < s->ev_used; i += 2) {
+            PNY_HIP(hipEventSynchronize(s->ev[i + 1]));
+            float ms = 0.f;
+            PNY_HIP(hipEventElapsedTime(&ms, s->ev[i], s->ev[i + 1]));
+            tot += ms;
+        }
+        *kernel_ms = s->timing ? tot : -1.0;
+    }
+    return PNY_OK;
+}
+
+}  // extern "C"

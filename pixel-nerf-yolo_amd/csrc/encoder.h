@@ -1,0 +1,39 @@
+// ResNet-34 trunk of SpatialEncoder (reference src/model/encoder.py:139-173) on gfx950.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <functional>
+#include <string>
+#include <vector>
+
+namespace pny {
+
+struct ConvLayer {
+    float* w = nullptr;      // packed MFMA A-operand order [Cout/32][J][64][4], K = (ky,kx,ci)
+    float* scale = nullptr;  // eval-mode batch norm: gamma / sqrt(var + eps)
+    float* shift = nullptr;  // beta - mean * scale
+    int cin = 0, cin_p = 0, cout = 0, k = 0, stride = 1, pad = 0, J = 0;
+};
+
+struct EncoderWeights {
+    ConvLayer conv1;
+    // layer1..3: per block conv1, conv2 and optional downsample
+    struct Block {
+        ConvLayer c1, c2, ds;
+        bool has_ds = false;
+    };
+    std::vector<Block> layers[3];
+    std::vector<float*> allocs;
+    using Getter = std::function<bool(const std::string&, const float**, std::vector<int64_t>*)>;
+    bool build(const Getter& get, const std::string& prefix, std::string* err);
+    void release();
+};
+
+void encoder_latent_size(int height, int width, int* hl, int* wl);
+size_t encoder_workspace_bytes(int ns, int height, int width);
+// images (ns,3,H,W) NCHW -> latent (ns, H0, W0, 512) channel-last
+bool encoder_forward(const EncoderWeights& w, const float* images, int ns, int height, int width, float* work,
+                     float* latent_nhwc, hipStream_t st, std::string* err);
+
+}  // namespace pny

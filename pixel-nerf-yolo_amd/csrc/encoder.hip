@@ -1,0 +1,408 @@
+// ResNet-34 trunk of SpatialEncoder for gfx950 (reference src/model/encoder.py:139-173,
+// num_layers = 4, use_first_pool, eval-mode batch norm; block layout = the public ResNet-34
+// BasicBlock [3,4,6] architecture -- torchvision itself is not in the tree).
+//
+// Every convolution is an implicit GEMM on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32),
+// out^T[cout][pixel] = W[cout][(ky,kx,ci)] * patch^T, with channel-last activations so that a
+// B-operand fragment (4 consecutive input channels of one tap) is one 16-byte load and an
+// accumulator quad (4 consecutive output channels of one pixel) is one 16-byte store; weights
+// are pre-packed in lane order like the MLP's (api.hip pack_layer).  Batch norm is applied in
+// the epilogue as x*scale + shift, then the residual add and relu -- one kernel per conv.
+// The pyramid is upsampled (bilinear, align_corners=True) and concatenated directly into the
+// channel-last latent the MLP kernel gathers from.
+#include <cmath>
+#include <cstring>
+
+#include "encoder.h"
+
+namespace pny {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvArgs {
+    const float* in;
+    const float* w;
+    const float* scale;
+    const float* shift;
+    const float* resid;
+    float* out;
+    int n, hin, win, cin_p, hout, wout, cout, k, stride, pad, J, relu;
+    long long npix;
+};
+
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = lane & 31, hh = lane >> 5;
+    const int tiles_n = a.cout / 64;
+    const long long tile = (long long)blockIdx.x * 4 + wave;
+    const long long tile_m = tile / tiles_n;
+    const int tile_n = (int)(tile - tile_m * tiles_n);
+    if (tile_m * 64 >= a.npix) return;
+
+    long long pix[2];
+    int iy0[2], ix0[2], img[2];
+    bool valid[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        long long p = tile_m * 64 + 32 * mt + m0;
+        valid[mt] = p < a.npix;
+        if (!valid[mt]) p = a.npix - 1;
+        pix[mt] = p;
+        const int per = a.hout * a.wout;
+        img[mt] = (int)(p / per);
+        const int r = (int)(p - (long long)img[mt] * per);
+        const int oy = r / a.wout, ox = r - oy * a.wout;
+        iy0[mt] = oy * a.stride - a.pad;
+        ix0[mt] = ox * a.stride - a.pad;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.f;
+
+    const float4* w0 = reinterpret_cast<const float4*>(a.w) + (size_t)(2 * tile_n) * a.J * 64 + lane;
+    const float4* w1 = w0 + (size_t)a.J * 64;
+    const int ntap = a.k * a.k;
+    for (int j = 0; j < a.J; ++j) {
+        const int k0 = 8 * j + 4 * hh;
+        const int tap = k0 / a.cin_p, ci = k0 - tap * a.cin_p;
+        const int ky = tap / a.k, kx = tap - ky * a.k;
+        const float4 a0 = w0[(size_t)j * 64], a1 = w1[(size_t)j * 64];
+        float4 b[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int iy = iy0[mt] + ky, ix = ix0[mt] + kx;
+            const bool ok = valid[mt] && tap < ntap && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
+            b[mt] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) b[mt] = *reinterpret_cast<const float4*>(a.in + (((size_t)img[mt] * a.hin + iy) * a.win + ix) * a.cin_p + ci);
+        }
+#define PNY_STEP(c)                                                                           \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c, b[0].c, acc[0][0], 0, 0, 0);       \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c, b[1].c, acc[0][1], 0, 0, 0);       \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c, b[0].c, acc[1][0], 0, 0, 0);       \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c, b[1].c, acc[1][1], 0, 0, 0);
+        PNY_STEP(x)
+        PNY_STEP(y)
+        PNY_STEP(z)
+        PNY_STEP(w)
+#undef PNY_STEP
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        if (!valid[mt]) continue;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = 64 * tile_n + 32 * nt + 8 * q + 4 * hh;
+                const float4 sc = *reinterpret_cast<const float4*>(a.scale + c);
+                const float4 sh = *reinterpret_cast<const float4*>(a.shift + c);
+                float4 v;
+                v.x = acc[nt][mt][4 * q + 0] * sc.x + sh.x;
+                v.y = acc[nt][mt][4 * q + 1] * sc.y + sh.y;
+                v.z = acc[nt][mt][4 * q + 2] * sc.z + sh.z;
+                v.w = acc[nt][mt][4 * q + 3] * sc.w + sh.w;
+                const size_t o = (size_t)pix[mt] * a.cout + c;
+                if (a.resid) {
+                    const float4 r = *reinterpret_cast<const float4*>(a.resid + o);
+                    v.x += r.x;
+                    v.y += r.y;
+                    v.z += r.z;
+                    v.w += r.w;
+                }
+                if (a.relu) {
+                    v.x = fmaxf(v.x, 0.f);
+                    v.y = fmaxf(v.y, 0.f);
+                    v.z = fmaxf(v.z, 0.f);
+                    v.w = fmaxf(v.w, 0.f);
+                }
+                *reinterpret_cast<float4*>(a.out + o) = v;
+            }
+    }
+}
+
+// (n,3,H,W) -> (n,H,W,4) with a zero 4th channel
+__global__ void image_to_nhwc4_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int hw) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)n * hw) return;
+    const int img = (int)(i / hw), p = (int)(i - (long long)img * hw);
+    const float* s = in + (size_t)img * 3 * hw + p;
+    *reinterpret_cast<float4*>(out + i * 4) = make_float4(s[0], s[hw], s[2 * (size_t)hw], 0.f);
+}
+
+// max_pool2d(3, stride 2, pad 1), channel-last
+__global__ void maxpool_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int hin, int win, int c,
+                               int hout, int wout) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int cq = c / 4;
+    if (i >= (long long)n * hout * wout * cq) return;
+    const int q = (int)(i % cq);
+    long long p = i / cq;
+    const int ox = (int)(p % wout);
+    p /= wout;
+    const int oy = (int)(p % hout), img = (int)(p / hout);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int dy = 0; dy < 3; ++dy)
+        for (int dx = 0; dx < 3; ++dx) {
+            const int iy = oy * 2 - 1 + dy, ix = ox * 2 - 1 + dx;
+            if (iy < 0 || iy >= hin || ix < 0 || ix >= win) continue;
+            const float4 v = *reinterpret_cast<const float4*>(in + (((size_t)img * hin + iy) * win + ix) * c + 4 * q);
+            m.x = fmaxf(m.x, v.x);
+            m.y = fmaxf(m.y, v.y);
+            m.z = fmaxf(m.z, v.z);
+            m.w = fmaxf(m.w, v.w);
+        }
+    *reinterpret_cast<float4*>(out + i * 4) = m;
+}
+
+// F.interpolate(bilinear, align_corners=True) of one pyramid level to (H0,W0), written at channel
+// offset coff of the 512-channel latent (reference encoder.py:160-169).
+__global__ void upsample_concat_kernel(const float* __restrict__ in, float* __restrict__ lat, int n, int hin, int win,
+                                       int c, int h0, int w0, int ctot, int coff) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int cq = c / 4;
+    if (i >= (long long)n * h0 * w0 * cq) return;
+    const int q = (int)(i % cq);
+    long long p = i / cq;
+    const int ox = (int)(p % w0);
+    p /= w0;
+    const int oy = (int)(p % h0), img = (int)(p / h0);
+    const float sy = h0 > 1 ? (float)(hin - 1) / (float)(h0 - 1) : 0.f;
+    const float sx = w0 > 1 ? (float)(win - 1) / (float)(w0 - 1) : 0.f;
+    const float fy = sy * (float)oy, fx = sx * (float)ox;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < hin - 1 ? 1 : 0), x1 = x0 + (x0 < win - 1 ? 1 : 0);
+    const float ly1 = fy - (float)y0, lx1 = fx - (float)x0;
+    const float ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
+    const float* b = in + (size_t)img * hin * win * c + 4 * q;
+    const float4 v00 = *reinterpret_cast<const float4*>(b + ((size_t)y0 * win + x0) * c);
+    const float4 v01 = *reinterpret_cast<const float4*>(b + ((size_t)y0 * win + x1) * c);
+    const float4 v10 = *reinterpret_cast<const float4*>(b + ((size_t)y1 * win + x0) * c);
+    const float4 v11 = *reinterpret_cast<const float4*>(b + ((size_t)y1 * win + x1) * c);
+    float4 o;
+    o.x = ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x);
+    o.y = ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y);
+    o.z = ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z);
+    o.w = ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w);
+    *reinterpret_cast<float4*>(lat + (((size_t)img * h0 + oy) * w0 + ox) * ctot + coff + 4 * q) = o;
+}
+
+// ----------------------------------------------------------------------------------- host side
+static bool upload(const std::vector<float>& v, float** out, std::vector<float*>& allocs, std::string* err) {
+    float* p = nullptr;
+    if (hipMalloc((void**)&p, v.size() * sizeof(float)) != hipSuccess ||
+        hipMemcpy(p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        *err = "device allocation / copy of encoder weights failed";
+        return false;
+    }
+    allocs.push_back(p);
+    *out = p;
+    return true;
+}
+
+static bool build_conv(const EncoderWeights::Getter& get, const std::string& conv, const std::string& bn, int cin,
+                       int cout, int k, int stride, int pad, ConvLayer& L, std::vector<float*>& allocs,
+                       std::string* err) {
+    const float* w = nullptr;
+    std::vector<int64_t> shp;
+    if (!get(conv + ".weight", &w, &shp) || shp != std::vector<int64_t>{cout, cin, k, k}) {
+        *err = "missing or mis-shaped '" + conv + ".weight'";
+        return false;
+    }
+    const float *g = nullptr, *b = nullptr, *mu = nullptr, *var = nullptr;
+    std::vector<int64_t> s1;
+    if (!get(bn + ".weight", &g, &s1) || !get(bn + ".bias", &b, &s1) || !get(bn + ".running_mean", &mu, &s1) ||
+        !get(bn + ".running_var", &var, &s1) || s1 != std::vector<int64_t>{cout}) {
+        *err = "missing or mis-shaped batch-norm tensors '" + bn + ".*'";
+        return false;
+    }
+    L.cin = cin;
+    L.cin_p = (cin + 3) / 4 * 4;
+    L.cout = cout;
+    L.k = k;
+    L.stride = stride;
+    L.pad = pad;
+    const int K = k * k * L.cin_p;
+    L.J = (K + 7) / 8;
+    // K order (ky, kx, ci); A-operand lane order as in api.hip pack_layer
+    std::vector<float> pk((size_t)(cout / 32) * L.J * 64 * 4);
+    size_t o = 0;
+    for (int nt = 0; nt < cout / 32; ++nt)
+        for (int j = 0; j < L.J; ++j)
+            for (int l = 0; l < 64; ++l)
+                for (int r = 0; r < 4; ++r) {
+                    const int n = 32 * nt + (l & 31), kk = 8 * j + 4 * (l >> 5) + r;
+                    const int tap = kk / L.cin_p, ci = kk % L.cin_p;
+                    float val = 0.f;
+                    if (tap < k * k && ci < cin) val = w[(((size_t)n * cin + ci) * k + tap / k) * k + tap % k];
+                    pk[o++] = val;
+                }
+    std::vector<float> sc(cout), sh(cout);
+    for (int c = 0; c < cout; ++c) {
+        // ATen's inference batch norm: alpha = weight / sqrt(var + eps); beta = bias - mean * alpha
+        const float invstd = 1.0f / std::sqrt(var[c] + 1e-5f);
+        sc[c] = g[c] * invstd;
+        sh[c] = b[c] - mu[c] * sc[c];
+    }
+    return upload(pk, &L.w, allocs, err) && upload(sc, &L.scale, allocs, err) && upload(sh, &L.shift, allocs, err);
+}
+
+bool EncoderWeights::build(const Getter& get, const std::string& pre, std::string* err) {
+    release();
+    if (!build_conv(get, pre + "conv1", pre + "bn1", 3, 64, 7, 2, 3, conv1, allocs, err)) return false;
+    const int couts[3] = {64, 128, 256}, nblk[3] = {3, 4, 6};
+    int cin = 64;
+    for (int li = 0; li < 3; ++li) {
+        layers[li].clear();
+        for (int b = 0; b < nblk[li]; ++b) {
+            Block blk;
+            const std::string p = pre + "layer" + std::to_string(li + 1) + "." + std::to_string(b) + ".";
+            const int stride = (b == 0 && li > 0) ? 2 : 1;
+            const int bc = (b == 0) ? cin : couts[li];
+            if (!build_conv(get, p + "conv1", p + "bn1", bc, couts[li], 3, stride, 1, blk.c1, allocs, err)) return false;
+            if (!build_conv(get, p + "conv2", p + "bn2", couts[li], couts[li], 3, 1, 1, blk.c2, allocs, err)) return false;
+            blk.has_ds = (b == 0 && (stride != 1 || bc != couts[li]));
+            if (blk.has_ds &&
+                !build_conv(get, p + "downsample.0", p + "downsample.1", bc, couts[li], 1, stride, 0, blk.ds, allocs, err))
+                return false;
+            layers[li].push_back(blk);
+        }
+        cin = couts[li];
+    }
+    return true;
+}
+
+void EncoderWeights::release() {
+    for (float* p : allocs) (void)hipFree(p);
+    allocs.clear();
+    for (auto& l : layers) l.clear();
+}
+
+static int conv_out(int in, int k, int s, int p) { return (in + 2 * p - k) / s + 1; }
+
+void encoder_latent_size(int height, int width, int* hl, int* wl) {
+    *hl = conv_out(height, 7, 2, 3);
+    *wl = conv_out(width, 7, 2, 3);
+}
+
+struct Dims {
+    int h[4], w[4];
+};
+static Dims pyramid(int height, int width) {
+    Dims d;
+    d.h[0] = conv_out(height, 7, 2, 3);
+    d.w[0] = conv_out(width, 7, 2, 3);
+    d.h[1] = conv_out(d.h[0], 3, 2, 1);
+    d.w[1] = conv_out(d.w[0], 3, 2, 1);
+    for (int i = 2; i < 4; ++i) {
+        d.h[i] = conv_out(d.h[i - 1], 3, 2, 1);
+        d.w[i] = conv_out(d.w[i - 1], 3, 2, 1);
+    }
+    return d;
+}
+
+static size_t align64(size_t x) { return (x + 63) & ~(size_t)63; }
+
+size_t encoder_workspace_bytes(int ns, int height, int width) {
+    const Dims d = pyramid(height, width);
+    size_t fl = align64((size_t)ns * height * width * 4);          // nhwc4 image
+    fl += align64((size_t)ns * d.h[0] * d.w[0] * 64);              // level 0
+    const int ch[4] = {64, 64, 128, 256};
+    for (int i = 1; i < 4; ++i) fl += 4 * align64((size_t)ns * d.h[i] * d.w[i] * ch[i]);  // x, tmp, out, ds
+    return fl * sizeof(float);
+}
+
+static bool run_conv(const ConvLayer& L, const float* in, int n, int hin, int win, const float* resid, int relu,
+                     float* out, hipStream_t st) {
+    ConvArgs a;
+    a.in = in;
+    a.w = L.w;
+    a.scale = L.scale;
+    a.shift = L.shift;
+    a.resid = resid;
+    a.out = out;
+    a.n = n;
+    a.hin = hin;
+    a.win = win;
+    a.cin_p = L.cin_p;
+    a.hout = conv_out(hin, L.k, L.stride, L.pad);
+    a.wout = conv_out(win, L.k, L.stride, L.pad);
+    a.cout = L.cout;
+    a.k = L.k;
+    a.stride = L.stride;
+    a.pad = L.pad;
+    a.J = L.J;
+    a.relu = relu;
+    a.npix = (long long)n * a.hout * a.wout;
+    const long long tiles = ((a.npix + 63) / 64) * (L.cout / 64);
+    hipLaunchKernelGGL(conv_mfma_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, a);
+    return hipGetLastError() == hipSuccess;
+}
+
+bool encoder_forward(const EncoderWeights& W, const float* images, int ns, int height, int width, float* work,
+                     float* lat, hipStream_t st, std::string* err) {
+    const Dims d = pyramid(height, width);
+    size_t off = 0;
+    auto carve = [&](size_t n) {
+        float* p = work + off;
+        off += align64(n);
+        return p;
+    };
+    float* img4 = carve((size_t)ns * height * width * 4);
+    float* l0 = carve((size_t)ns * d.h[0] * d.w[0] * 64);
+    const int ch[4] = {64, 64, 128, 256};
+    float* buf[4][4];
+    for (int i = 1; i < 4; ++i)
+        for (int b = 0; b < 4; ++b) buf[i][b] = carve((size_t)ns * d.h[i] * d.w[i] * ch[i]);
+
+    auto bad = [&]() {
+        *err = std::string("encoder kernel launch failed: ") + hipGetErrorString(hipGetLastError());
+        return false;
+    };
+    const long long npx = (long long)ns * height * width;
+    hipLaunchKernelGGL(image_to_nhwc4_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, st, images, img4, ns,
+                       height * width);
+    if (!run_conv(W.conv1, img4, ns, height, width, nullptr, 1, l0, st)) return bad();
+    const long long npool = (long long)ns * d.h[1] * d.w[1] * 16;
+    hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)((npool + 255) / 256)), dim3(256), 0, st, l0, buf[1][0], ns,
+                       d.h[0], d.w[0], 64, d.h[1], d.w[1]);
+
+    const float* level_out[4] = {l0, nullptr, nullptr, nullptr};
+    const float* x = buf[1][0];
+    int hin = d.h[1], win = d.w[1];
+    for (int li = 0; li < 3; ++li) {
+        const int lv = li + 1;
+        // buffers of a level: [0],[2] alternate as block outputs ([1][0] first holds the pooled
+        // input), [1] = conv1 output, [3] = downsampled identity
+        for (size_t b = 0; b < W.layers[li].size(); ++b) {
+            const EncoderWeights::Block& B = W.layers[li][b];
+            const float* idt = x;
+            if (B.has_ds) {
+                if (!run_conv(B.ds, x, ns, hin, win, nullptr, 0, buf[lv][3], st)) return bad();
+                idt = buf[lv][3];
+            }
+            if (!run_conv(B.c1, x, ns, hin, win, nullptr, 1, buf[lv][1], st)) return bad();
+            const int ho = conv_out(hin, 3, B.c1.stride, 1), wo = conv_out(win, 3, B.c1.stride, 1);
+            float* dst = (x == buf[lv][0]) ? buf[lv][2] : buf[lv][0];
+            if (!run_conv(B.c2, buf[lv][1], ns, ho, wo, idt, 1, dst, st)) return bad();
+            x = dst;
+            hin = ho;
+            win = wo;
+        }
+        level_out[lv] = x;
+    }
+    // pyramid -> latent: every level resampled to level 0's size (identity for level 0)
+    const int coff[4] = {0, 64, 128, 256};
+    for (int lv = 0; lv < 4; ++lv) {
+        const long long np = (long long)ns * d.h[0] * d.w[0] * (ch[lv] / 4);
+        hipLaunchKernelGGL(upsample_concat_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st,
+                           level_out[lv], lat, ns, d.h[lv], d.w[lv], ch[lv], d.h[0], d.w[0], 512, coff[lv]);
+    }
+    if (hipGetLastError() != hipSuccess) return bad();
+    return true;
+}
+
+}  // namespace pny

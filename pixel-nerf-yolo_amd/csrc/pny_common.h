@@ -1,0 +1,90 @@
+// Shared declarations of libpnyolo's translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/pnyolo.h"
+
+namespace pny {
+
+constexpr int HID = 512;        // d_hidden this build is specialised for
+constexpr int TM = 64;          // samples (GEMM columns) per workgroup tile
+constexpr int MLP_THREADS = 512;
+constexpr int MAX_BLOCKS = 8;
+constexpr int MAX_VIEWS = 16;
+constexpr int D_IN_PAD = 48;    // 42 inputs padded to a multiple of 8 (one MFMA k-group pair)
+constexpr int ACT_KG = 128;     // k-groups (4 features each) held by the LDS activation buffer
+constexpr int MLP_LDS_BYTES = ACT_KG * TM * 16 + 2048;  // activations + per-sample tap table
+
+// World->camera pose and intrinsics of one source view (reference models.py:74-87 buffers).
+struct Cam {
+    float w2c[12];  // 3x4 row-major
+    float fx, fy, cx, cy;
+};
+
+// Device pointers of one packed ResnetFC (reference resnetfc.py:66-132).  512-wide layers are
+// stored in MFMA A-operand order (see pack_layer in api.hip); lin_out stays row-major.
+struct MlpWeights {
+    const float* w_in;
+    const float* b_in;
+    const float* w_z[MAX_BLOCKS];
+    const float* b_z[MAX_BLOCKS];
+    const float* w_fc0[MAX_BLOCKS];
+    const float* b_fc0[MAX_BLOCKS];
+    const float* w_fc1[MAX_BLOCKS];
+    const float* b_fc1[MAX_BLOCKS];
+    const float* w_out;
+    const float* b_out;
+};
+
+struct MlpArgs {
+    MlpWeights w;
+    const float* latent;  // (NS, Hl, Wl, L) channel-last
+    const Cam* cams;      // NS entries
+    // point source: mode 0 = explicit points, mode 1 = rays + depths (point = o + z d)
+    const float* xyz;
+    const float* dirs;
+    const float* rays;
+    const float* z;
+    float* out;       // (n_points, d_out)
+    float* scratch;   // gridDim.x * TM * HID floats: cross-view running sum
+    long long n_points;
+    int K;            // samples per ray (mode 1)
+    int mode;
+    int NS, L, Hl, Wl;
+    int n_blocks, combine_layer, d_out, yolo, num_freqs;
+    float freq_factor;
+    float sx, sy;     // latent_scaling / image_size (reference encoder.py:97)
+    int n_tiles;
+};
+
+void launch_mlp(const MlpArgs& a, int grid, hipStream_t st);
+int mlp_max_grid();
+
+// render_kernels.hip
+void launch_sample_coarse(const float* rays, long long n, int kc, int lindisp, const float* u, uint64_t seed,
+                          float* z, hipStream_t st);
+void launch_composite(const float* rays, const float* z, const float* samp, long long n, int k, int white,
+                      float* w, float* rgb, float* depth, hipStream_t st);
+void launch_sample_fine(const float* rays, const float* zc, const float* w, const float* depth, long long n,
+                        int kc, int kf, int kfd, float depth_std, int lindisp, const float* u, const float* u2,
+                        const float* g, uint64_t seed, float* zout, hipStream_t st);
+void launch_yolo_aggregate(const float* raw, long long n, int k, int na, float* out, hipStream_t st);
+void launch_gen_rays(const float* cam16, int b, int w, int h, float znear, float zfar, int yolo, float* out,
+                     hipStream_t st);
+void launch_nchw_to_nhwc(const float* in, float* out, int n, int c, int hw, hipStream_t st);
+void launch_nhwc_to_nchw(const float* in, float* out, int n, int c, int hw, hipStream_t st);
+
+// error plumbing
+void set_error(const std::string& msg);
+int hip_fail(hipError_t e, const char* what);
+
+}  // namespace pny
+
+#define PNY_HIP(call)                                          \
+    do {                                                       \
+        hipError_t e_ = (call);                                \
+        if (e_ != hipSuccess) return pny::hip_fail(e_, #call); \
+    } while (0)

@@ -1,0 +1,370 @@
+// Ray / sampling / compositing kernels of the renderer (gfx950).  These are HBM- and
+// latency-trivial next to the MLP (~1 % of the reference's time); they exist so
+// that a render call never leaves the device and never launches an ATen op.
+#include "pny_common.h"
+
+namespace pny {
+
+// ------------------------------------------------------------------ counter-based RNG (perf mode)
+// Philox4x32-10 (Salmon et al., SC'11), written out from the published round function.
+struct Philox {
+    uint32_t key[2];
+    __device__ Philox(uint64_t seed) {
+        key[0] = (uint32_t)seed;
+        key[1] = (uint32_t)(seed >> 32);
+    }
+    __device__ void draw(uint64_t index, uint32_t stream, uint32_t (&out)[4]) const {
+        uint32_t c[4] = {(uint32_t)index, (uint32_t)(index >> 32), stream, 0x9E3779B9u};
+        uint32_t k0 = key[0], k1 = key[1];
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+            const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+            const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+            const uint32_t n1 = (uint32_t)p1;
+            const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+            const uint32_t n3 = (uint32_t)p0;
+            c[0] = n0;
+            c[1] = n1;
+            c[2] = n2;
+            c[3] = n3;
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        out[0] = c[0];
+        out[1] = c[1];
+        out[2] = c[2];
+        out[3] = c[3];
+    }
+};
+__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }  // [0,1)
+__device__ __forceinline__ float uniform_at(uint64_t seed, uint32_t stream, uint64_t idx) {
+    uint32_t r[4];
+    Philox(seed).draw(idx >> 2, stream, r);
+    return u01(r[idx & 3]);
+}
+__device__ __forceinline__ float normal_at(uint64_t seed, uint32_t stream, uint64_t idx) {
+    uint32_t r[4];
+    Philox(seed).draw(idx >> 1, stream, r);
+    const float u1 = 1.0f - u01(r[2 * (idx & 1)]);  // (0,1]
+    const float u2 = u01(r[2 * (idx & 1) + 1]);
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+enum { STREAM_COARSE = 1, STREAM_FINE = 2, STREAM_FINE2 = 3, STREAM_DEPTH = 4 };
+
+// ------------------------------------------------------------------ sample_coarse
+// reference nerf.py:104-121: t = linspace(0, 1-1/Kc, Kc)[k] + u/Kc ; z = near(1-t) + far t
+__device__ __forceinline__ float lerp_depth(float near, float far, float t, int lindisp) {
+    if (!lindisp) return near * (1.0f - t) + far * t;
+    return 1.0f / (1.0f / near * (1.0f - t) + 1.0f / far * t);
+}
+
+__global__ void sample_coarse_kernel(const float* __restrict__ rays, long long n, int kc, int lindisp,
+                                     const float* __restrict__ u, uint64_t seed, float step, float end,
+                                     float* __restrict__ z) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * kc) return;
+    const long long ray = i / kc;
+    const int k = (int)(i - ray * kc);
+    // torch.linspace(0, 1-step, Kc): start + k * ((end - start)/(Kc-1)), symmetric about the middle;
+    // step and end are the reference's Python doubles rounded to fp32 on the host
+    const float inc = kc > 1 ? end / (float)(kc - 1) : 0.f;
+    const float lin = (k < kc / 2) ? (float)k * inc : end - (float)(kc - 1 - k) * inc;
+    const float uu = u ? u[i] : uniform_at(seed, STREAM_COARSE, (uint64_t)i);
+    const float t = lin + uu * step;
+    z[i] = lerp_depth(rays[ray * 8 + 6], rays[ray * 8 + 7], t, lindisp);
+}
+
+void launch_sample_coarse(const float* rays, long long n, int kc, int lindisp, const float* u, uint64_t seed,
+                          float* z, hipStream_t st) {
+    const long long tot = n * kc;
+    if (tot == 0) return;
+    const double dstep = 1.0 / (double)kc;
+    hipLaunchKernelGGL(sample_coarse_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, rays, n, kc,
+                       lindisp, u, seed, (float)dstep, (float)(1.0 - dstep), z);
+}
+
+// ------------------------------------------------------------------ composite
+// reference nerf.py:184-188, 229-250.  One wavefront per ray, one sample per lane (chunks of 64
+// with a carried transmittance): alpha per lane, transmittance = exclusive prefix product by a
+// log-step wavefront scan, weighted sums by butterfly reduction.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void composite_kernel(const float* __restrict__ rays, const float* __restrict__ z,
+                                                        const float* __restrict__ samp, long long n, int K,
+                                                        int white, float* __restrict__ wout,
+                                                        float* __restrict__ rgb, float* __restrict__ depth) {
+    const int lane = threadIdx.x & 63;
+    const long long ray = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= n) return;
+    const float far = rays[ray * 8 + 7];
+    const float* zr = z + ray * K;
+    const float4* sr = reinterpret_cast<const float4*>(samp) + ray * K;
+    float carry = 1.0f;  // T before the first sample of the chunk
+    float ar = 0.f, ag = 0.f, ab = 0.f, ad = 0.f, aw = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        const int k = k0 + lane;
+        const bool on = k < K;
+        float alpha = 0.f, zk = 0.f;
+        float4 s = {0.f, 0.f, 0.f, 0.f};
+        if (on) {
+            zk = zr[k];
+            const float znext = (k + 1 < K) ? zr[k + 1] : far;
+            s = sr[k];
+            const float delta = znext - zk;
+            alpha = 1.0f - expf(-delta * fmaxf(s.w, 0.f));
+        }
+        // inclusive product scan of (1 - alpha + 1e-10)
+        float pprod = on ? (1.0f - alpha + 1e-10f) : 1.0f;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float up = __shfl_up(pprod, o, 64);
+            if (lane >= o) pprod *= up;
+        }
+        float excl = __shfl_up(pprod, 1, 64);
+        if (lane == 0) excl = 1.0f;
+        const float T = carry * excl;
+        const float w = alpha * T;
+        if (on && wout) wout[ray * K + k] = w;
+        ar += w * s.x;
+        ag += w * s.y;
+        ab += w * s.z;
+        ad += w * zk;
+        aw += w;
+        carry *= __shfl(pprod, 63, 64);
+    }
+    ar = wave_sum(ar);
+    ag = wave_sum(ag);
+    ab = wave_sum(ab);
+    ad = wave_sum(ad);
+    aw = wave_sum(aw);
+    if (lane == 0) {
+        if (white) {  // rgb + 1 - sum(w), reference nerf.py:247-250
+            ar = ar + 1.0f - aw;
+            ag = ag + 1.0f - aw;
+            ab = ab + 1.0f - aw;
+        }
+        if (rgb) {
+            rgb[ray * 3 + 0] = ar;
+            rgb[ray * 3 + 1] = ag;
+            rgb[ray * 3 + 2] = ab;
+        }
+        if (depth) depth[ray] = ad;
+    }
+}
+
+void launch_composite(const float* rays, const float* z, const float* samp, long long n, int k, int white,
+                      float* w, float* rgb, float* depth, hipStream_t st) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(composite_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, rays, z, samp, n, k, white,
+                       w, rgb, depth);
+}
+
+// ------------------------------------------------------------------ sample_fine + depth + sort
+// reference nerf.py:126-167, 291-301.  One ray per lane, strictly sequential per-ray arithmetic in
+// the reference's CPU order (cumsum left to right, searchsorted(right=True)), because bin
+// selection is discontinuous in the cdf (hard part 5).  Per-ray arrays live in LDS,
+// transposed ([k][lane]) so that every access is conflict-free.
+constexpr int FINE_LANES = 64;
+
+__global__ __launch_bounds__(FINE_LANES) void sample_fine_kernel(
+    const float* __restrict__ rays, const float* __restrict__ zc, const float* __restrict__ wts,
+    const float* __restrict__ depth, long long n, int kc, int kf, int kfd, float depth_std, int lindisp,
+    const float* __restrict__ u, const float* __restrict__ u2, const float* __restrict__ g, uint64_t seed,
+    float* __restrict__ zout) {
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x;
+    const long long ray = (long long)blockIdx.x * FINE_LANES + lane;
+    const int ktot = kc + kf;
+    float* cdf = lds;                                  // [(kc+1)][64]
+    float* zs = lds + (size_t)(kc + 1) * FINE_LANES;   // [ktot][64]
+    if (ray >= n) return;
+    const float near = rays[ray * 8 + 6], far = rays[ray * 8 + 7];
+    const int kimp = kf - kfd;
+
+    // pdf / cdf: weights + 1e-5, normalised, running sum with a leading 0 (nerf.py:136-139)
+    float tot = 0.f;
+    for (int k = 0; k < kc; ++k) tot += wts[ray * kc + k] + 1e-5f;
+    float run = 0.f;
+    cdf[lane] = 0.f;
+    for (int k = 0; k < kc; ++k) {
+        run += (wts[ray * kc + k] + 1e-5f) / tot;
+        cdf[(k + 1) * FINE_LANES + lane] = run;
+    }
+    for (int k = 0; k < kc; ++k) zs[k * FINE_LANES + lane] = zc[ray * kc + k];
+
+    // importance samples (nerf.py:141-153)
+    for (int i = 0; i < kimp; ++i) {
+        const long long idx = ray * kimp + i;
+        const float uu = u ? u[idx] : uniform_at(seed, STREAM_FINE, (uint64_t)idx);
+        const float vv = u2 ? u2[idx] : uniform_at(seed, STREAM_FINE2, (uint64_t)idx);
+        // searchsorted(cdf, u, right=True): first index with cdf[index] > u, over kc+1 entries
+        int lo = 0, hi = kc + 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cdf[mid * FINE_LANES + lane] > uu)
+                hi = mid;
+            else
+                lo = mid + 1;
+        }
+        float ind = (float)lo - 1.0f;
+        ind = fmaxf(ind, 0.0f);
+        const float t = (ind + vv) / (float)kc;
+        zs[(kc + i) * FINE_LANES + lane] = lerp_depth(near, far, t, lindisp);
+    }
+    // depth samples (nerf.py:163-166): clamp(depth + g*std, near, far)
+    for (int i = 0; i < kfd; ++i) {
+        const long long idx = ray * kfd + i;
+        const float gg = g ? g[idx] : normal_at(seed, STREAM_DEPTH, (uint64_t)idx);
+        float zz = depth[ray] + gg * depth_std;
+        zz = fmaxf(fminf(zz, far), near);
+        zs[(kc + kimp + i) * FINE_LANES + lane] = zz;
+    }
+    // sort (nerf.py:301): the first kc entries are already ascending (one sample per stratum);
+    // insert the kf new ones.
+    for (int i = kc; i < ktot; ++i) {
+        const float key = zs[i * FINE_LANES + lane];
+        int j = i - 1;
+        while (j >= 0) {
+            const float c = zs[j * FINE_LANES + lane];
+            if (!(c > key)) break;
+            zs[(j + 1) * FINE_LANES + lane] = c;
+            --j;
+        }
+        zs[(j + 1) * FINE_LANES + lane] = key;
+    }
+    for (int k = 0; k < ktot; ++k) zout[ray * ktot + k] = zs[k * FINE_LANES + lane];
+}
+
+void launch_sample_fine(const float* rays, const float* zc, const float* w, const float* depth, long long n, int kc,
+                        int kf, int kfd, float depth_std, int lindisp, const float* u, const float* u2,
+                        const float* g, uint64_t seed, float* zout, hipStream_t st) {
+    if (n == 0) return;
+    const size_t lds = (size_t)(kc + 1 + kc + kf) * FINE_LANES * sizeof(float);
+    static size_t max_set = 0;
+    if (lds > max_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sample_fine_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        max_set = lds;
+    }
+    hipLaunchKernelGGL(sample_fine_kernel, dim3((unsigned)((n + FINE_LANES - 1) / FINE_LANES)), dim3(FINE_LANES), lds,
+                       st, rays, zc, w, depth, n, kc, kf, kfd, depth_std, lindisp, u, u2, g, seed, zout);
+}
+
+// ------------------------------------------------------------------ YOLO aggregation
+// reference yolo.py:96-114: p = sigmoid(out[...,0]); [max_k p, sum_k p v / (sum_k p + 1e-5)].
+// One wavefront per (ray, anchor); lanes stride over the K samples.
+__global__ __launch_bounds__(256) void yolo_aggregate_kernel(const float* __restrict__ raw, long long n, int K,
+                                                             int na, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= n * na) return;
+    const long long ray = item / na;
+    const int a = (int)(item - ray * na);
+    float ps = 0.f, pm = 0.f, v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = lane; k < K; k += 64) {
+        const float* r = raw + ((ray * K + k) * na + a) * 7;
+        const float p = 1.0f / (1.0f + expf(-r[0]));
+        ps += p;
+        pm = fmaxf(pm, p);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) v[i] += r[1 + i] * p;
+    }
+    ps = wave_sum(ps);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pm = fmaxf(pm, __shfl_xor(pm, o, 64));
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[i] = wave_sum(v[i]);
+    if (lane == 0) {
+        float* o = out + item * 7;
+        o[0] = pm;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) o[1 + i] = v[i] / (ps + 1e-5f);
+    }
+}
+
+void launch_yolo_aggregate(const float* raw, long long n, int k, int na, float* out, hipStream_t st) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(yolo_aggregate_kernel, dim3((unsigned)((n * na + 3) / 4)), dim3(256), 0, st, raw, n, k, na,
+                       out);
+}
+
+// ------------------------------------------------------------------ ray generation
+// cam16 per image: [M 3x3 row-major (pixel-dir -> world), origin(3), fx, fy, cx, cy].
+//   yolo=0 (reference util.py:115-145,240-278): d = normalize((x-cx)/fx, -(y-cy)/fy, -1), dir = R d
+//   yolo=1 (reference util.py:808-876): d = Kinv [x+.49, y+.49, 1] (host passes Kinv entries in
+//   fx,fy,cx,cy as 1/fx, 1/fy, -cx/fx, -cy/fy), dir = Einv[:3,:3] d, not normalised.
+__global__ void gen_rays_kernel(const float* __restrict__ cam16, int b, int w, int h, float znear, float zfar,
+                                int yolo, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long per = (long long)w * h;
+    if (i >= per * b) return;
+    const int img = (int)(i / per);
+    const int pix = (int)(i - img * per);
+    const int y = pix / w, x = pix - y * w;
+    const float* c = cam16 + img * 16;
+    float d0, d1, d2;
+    if (!yolo) {
+        d0 = ((float)x - c[14]) / c[12];
+        d1 = -(((float)y - c[15]) / c[13]);
+        d2 = -1.0f;
+        const float nrm = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+        d0 /= nrm;
+        d1 /= nrm;
+        d2 /= nrm;
+    } else {
+        const float px = (float)x + 0.49f, py = (float)y + 0.49f;
+        d0 = c[12] * px + c[14];
+        d1 = c[13] * py + c[15];
+        d2 = 1.0f;
+    }
+    float* o = out + i * 8;
+    o[0] = c[9];
+    o[1] = c[10];
+    o[2] = c[11];
+    o[3] = c[0] * d0 + c[1] * d1 + c[2] * d2;
+    o[4] = c[3] * d0 + c[4] * d1 + c[5] * d2;
+    o[5] = c[6] * d0 + c[7] * d1 + c[8] * d2;
+    o[6] = znear;
+    o[7] = zfar;
+}
+
+void launch_gen_rays(const float* cam16, int b, int w, int h, float znear, float zfar, int yolo, float* out,
+                     hipStream_t st) {
+    const long long tot = (long long)b * w * h;
+    if (tot == 0) return;
+    hipLaunchKernelGGL(gen_rays_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, cam16, b, w, h, znear,
+                       zfar, yolo, out);
+}
+
+// ------------------------------------------------------------------ layout repack
+// (n, c, hw) <-> (n, hw, c) through a 32x32 LDS tile so that both sides are coalesced.
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                        int rows, int cols) {
+    __shared__ float tile[32][33];
+    const size_t base = (size_t)blockIdx.z * rows * cols;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        if (r < rows && c < cols) tile[i][tx] = in[base + (size_t)r * cols + c];
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (r < rows && c < cols) out[base + (size_t)c * rows + r] = tile[tx][i];
+    }
+}
+
+void launch_nchw_to_nhwc(const float* in, float* out, int n, int c, int hw, hipStream_t st) {
+    hipLaunchKernelGGL(transpose_kernel, dim3((hw + 31) / 32, (c + 31) / 32, n), dim3(256), 0, st, in, out, c, hw);
+}
+void launch_nhwc_to_nchw(const float* in, float* out, int n, int c, int hw, hipStream_t st) {
+    hipLaunchKernelGGL(transpose_kernel, dim3((c + 31) / 32, (hw + 31) / 32, n), dim3(256), 0, st, in, out, hw, c);
+}
+
+}  // namespace pny

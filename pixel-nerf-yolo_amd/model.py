@@ -1,0 +1,438 @@
+"""
+Host-side mirror of the reference's model layer (src/model/): ``make_model`` and
+``PixelNeRFNet`` with the same constructor, ``encode`` / ``forward`` / ``load_weights``
+signatures and the same state_dict key names, executing on libpnyolo.so.
+
+torch is used for what it is good at here: holding parameters / checkpoints (state_dict
+compatibility with the reference's ``pixel_nerf_latest`` files), device memory and streams.
+No torch operator runs on the hot path: ``encode`` and ``forward`` hand raw device pointers to
+the C ABI (include/pnyolo.h).  Forward only -- a call under autograd raises (backward is the
+"next" row of SURVEY.md 8f).
+"""
+import ctypes as C
+import os
+import os.path as osp
+import warnings
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import lib as _lib
+from .lib import ModelDesc, check, ptr, stream_of
+
+
+# ------------------------------------------------------------------ parameter containers
+class _ResnetBlockFC(nn.Module):
+    """Parameters of one block; init as reference src/model/resnetfc.py:19-51."""
+
+    def __init__(self, size):
+        super().__init__()
+        self.fc_0 = nn.Linear(size, size)
+        self.fc_1 = nn.Linear(size, size)
+        nn.init.constant_(self.fc_0.bias, 0.0)
+        nn.init.kaiming_normal_(self.fc_0.weight, a=0, mode="fan_in")
+        nn.init.constant_(self.fc_1.bias, 0.0)
+        nn.init.zeros_(self.fc_1.weight)
+
+
+class ResnetFC(nn.Module):
+    """Parameter container with the reference's names / shapes / init
+    (src/model/resnetfc.py:66-132, from_conf :188-205).  The arithmetic lives in csrc/mlp.hip."""
+
+    def __init__(self, d_in, d_out=4, n_blocks=5, d_latent=0, d_hidden=128, beta=0.0, combine_layer=1000,
+                 combine_type="average", use_spade=False):
+        super().__init__()
+        if beta > 0 or use_spade or combine_type != "average":
+            raise NotImplementedError("libpnyolo supports ReLU, no SPADE, average combine (the shipped configs)")
+        self.lin_in = nn.Linear(d_in, d_hidden)
+        nn.init.constant_(self.lin_in.bias, 0.0)
+        nn.init.kaiming_normal_(self.lin_in.weight, a=0, mode="fan_in")
+        self.lin_out = nn.Linear(d_hidden, d_out)
+        nn.init.constant_(self.lin_out.bias, 0.0)
+        nn.init.kaiming_normal_(self.lin_out.weight, a=0, mode="fan_in")
+        self.n_blocks, self.d_latent, self.d_in, self.d_out, self.d_hidden = n_blocks, d_latent, d_in, d_out, d_hidden
+        self.combine_layer, self.combine_type, self.use_spade = combine_layer, combine_type, use_spade
+        self.blocks = nn.ModuleList([_ResnetBlockFC(d_hidden) for _ in range(n_blocks)])
+        if d_latent != 0:
+            n_lin_z = min(combine_layer, n_blocks)
+            self.lin_z = nn.ModuleList([nn.Linear(d_latent, d_hidden) for _ in range(n_lin_z)])
+            for i in range(n_lin_z):
+                nn.init.constant_(self.lin_z[i].bias, 0.0)
+                nn.init.kaiming_normal_(self.lin_z[i].weight, a=0, mode="fan_in")
+
+    @classmethod
+    def from_conf(cls, conf, d_in, **kwargs):
+        if not conf.get_bool("yolo", False):
+            d_out = conf.get_int("d_out", 4)
+        else:
+            d_out = conf.get_int("d_out", 7) * conf.get_int("num_anchors_per_scale", 3)
+        return cls(d_in, d_out=d_out, n_blocks=conf.get_int("n_blocks", 5), d_hidden=conf.get_int("d_hidden", 128),
+                   beta=conf.get_float("beta", 0.0), combine_layer=conf.get_int("combine_layer", 1000),
+                   combine_type=conf.get_string("combine_type", "average"),
+                   use_spade=conf.get_bool("use_spade", False), **kwargs)
+
+    def forward(self, *a, **k):
+        raise RuntimeError("ResnetFC is evaluated inside libpnyolo's fused kernel; call PixelNeRFNet.forward")
+
+
+class PositionalEncoding(nn.Module):
+    """Buffers `_freqs`, `_phases` as in reference src/model/code.py:11-28 (checkpoint keys)."""
+
+    def __init__(self, num_freqs=6, d_in=3, freq_factor=np.pi, include_input=True):
+        super().__init__()
+        self.num_freqs, self.d_in, self.freq_factor, self.include_input = num_freqs, d_in, freq_factor, include_input
+        freqs = freq_factor * 2.0 ** torch.arange(0, num_freqs)
+        self.d_out = num_freqs * 2 * d_in + (d_in if include_input else 0)
+        self.register_buffer("_freqs", torch.repeat_interleave(freqs, 2).view(1, -1, 1))
+        ph = torch.zeros(2 * num_freqs)
+        ph[1::2] = np.pi * 0.5
+        self.register_buffer("_phases", ph.view(1, -1, 1))
+
+    @classmethod
+    def from_conf(cls, conf, d_in=3):
+        return cls(conf.get_int("num_freqs", 6), d_in, conf.get_float("freq_factor", np.pi),
+                   conf.get_bool("include_input", True))
+
+
+def _basic_block(cin, cout, stride):
+    blk = nn.Module()
+    blk.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+    blk.bn1 = nn.BatchNorm2d(cout)
+    blk.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+    blk.bn2 = nn.BatchNorm2d(cout)
+    if stride != 1 or cin != cout:
+        blk.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+    return blk
+
+
+def _resnet34_params():
+    """Parameter container with the ResNet-34 key names the reference's checkpoints hold
+    (`encoder.model.*`).  layer4 is carried for strict state_dict loading only."""
+    m = nn.Module()
+    m.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+    m.bn1 = nn.BatchNorm2d(64)
+    cin = 64
+    for li, (cout, n) in enumerate([(64, 3), (128, 4), (256, 6), (512, 3)], start=1):
+        setattr(m, "layer%d" % li, nn.Sequential(
+            *[_basic_block(cin if b == 0 else cout, cout, 2 if (b == 0 and li > 1) else 1) for b in range(n)]))
+        cin = cout
+    return m
+
+
+class SpatialEncoder(nn.Module):
+    """Configuration + parameters of the spatial encoder (reference src/model/encoder.py:13-77).
+    backbone 'resnet34' runs in csrc/encoder.hip; backbone 'custom' (YOLOv7, whose source and
+    weights are outside the reference tree) has no kernels: its output must be supplied through
+    ``PixelNeRFNet.encode(..., latent=...)``."""
+
+    def __init__(self, backbone="resnet34", pretrained=True, num_layers=4, index_interp="bilinear",
+                 index_padding="border", upsample_interp="bilinear", feature_scale=1.0, use_first_pool=True,
+                 norm_type="batch"):
+        super().__init__()
+        self.use_custom_resnet = backbone == "custom"
+        if self.use_custom_resnet:
+            self.latent_size = 1792  # reference custom_encoder.py:22
+            self.model = nn.Module()
+        else:
+            if backbone != "resnet34" or num_layers != 4 or norm_type != "batch" or not use_first_pool \
+                    or feature_scale != 1.0:
+                raise NotImplementedError("libpnyolo's encoder kernels cover backbone=resnet34, num_layers=4, batch "
+                                          "norm, use_first_pool, feature_scale=1 (the shipped multi-view configs)")
+            self.latent_size = [0, 64, 128, 256, 512, 1024][num_layers]
+            self.model = _resnet34_params()
+            # `pretrained` ImageNet weights cannot be downloaded here; they arrive via load_weights
+        if index_interp != "bilinear" or index_padding != "zeros" or upsample_interp != "bilinear":
+            raise NotImplementedError("libpnyolo supports bilinear indexing with zeros padding "
+                                      "(conf/default.conf:49 of the reference)")
+        self.num_layers = num_layers
+        self.index_interp, self.index_padding, self.upsample_interp = index_interp, index_padding, upsample_interp
+
+    @classmethod
+    def from_conf(cls, conf):
+        return cls(conf.get_string("backbone"), pretrained=conf.get_bool("pretrained", True),
+                   num_layers=conf.get_int("num_layers", 4), index_interp=conf.get_string("index_interp", "bilinear"),
+                   index_padding=conf.get_string("index_padding", "border"),
+                   upsample_interp=conf.get_string("upsample_interp", "bilinear"),
+                   feature_scale=conf.get_float("feature_scale", 1.0),
+                   use_first_pool=conf.get_bool("use_first_pool", True))
+
+
+def make_mlp(conf, d_in, d_latent=0, allow_empty=False, **kwargs):
+    """reference src/model/model_util.py:5-15"""
+    mlp_type = conf.get_string("type", "mlp")
+    if mlp_type == "resnet":
+        return ResnetFC.from_conf(conf, d_in, d_latent=d_latent, **kwargs)
+    if mlp_type == "empty" and allow_empty:
+        return None
+    raise NotImplementedError("Unsupported MLP type (libpnyolo implements type = resnet)")
+
+
+def make_encoder(conf, **kwargs):
+    """reference src/model/model_util.py:18-26"""
+    if conf.get_string("type", "spatial") != "spatial":
+        raise NotImplementedError("Unsupported encoder type")
+    return SpatialEncoder.from_conf(conf, **kwargs)
+
+
+# ------------------------------------------------------------------ the model
+class PixelNeRFNet(nn.Module):
+    """Drop-in for reference src/model/models.py:15 (constructor :16-90, encode :92-151,
+    forward :153-318, load/save_weights :320-370)."""
+
+    def __init__(self, conf, stop_encoder_grad=False):
+        super().__init__()
+        self.encoder = make_encoder(conf["encoder"])
+        self.use_encoder = conf.get_bool("use_encoder", True)
+        self.use_xyz = conf.get_bool("use_xyz", False)
+        self.normalize_z = conf.get_bool("normalize_z", True)
+        self.stop_encoder_grad = stop_encoder_grad
+        self.use_code = conf.get_bool("use_code", False)
+        self.use_code_viewdirs = conf.get_bool("use_code_viewdirs", True)
+        self.use_viewdirs = conf.get_bool("use_viewdirs", False)
+        self.use_global_encoder = conf.get_bool("use_global_encoder", False)
+        if not (self.use_encoder and self.use_xyz and self.normalize_z and self.use_code and self.use_viewdirs
+                and not self.use_code_viewdirs and not self.use_global_encoder):
+            raise NotImplementedError(
+                "libpnyolo implements the shipped flag set: use_encoder, use_xyz, normalize_z, use_code, "
+                "use_viewdirs, not use_code_viewdirs, no global encoder (conf/default.conf of the reference)")
+        d_latent = self.encoder.latent_size
+        self.code = PositionalEncoding.from_conf(conf["code"], d_in=3)
+        if not self.code.include_input:
+            raise NotImplementedError("code.include_input = False is not supported")
+        d_in = self.code.d_out + 3
+        self.latent_size = self.encoder.latent_size
+        self.mlp_coarse = make_mlp(conf["mlp_coarse"], d_in, d_latent)
+        # assignable: eval.py:140 of the reference sets `net.mlp_fine = None` for coarse-only runs
+        self.mlp_fine = make_mlp(conf["mlp_fine"], d_in, d_latent, allow_empty=True)
+        self.yolo = conf.get_bool("mlp_coarse.yolo", False)
+        self.d_in = d_in
+        if not self.yolo:
+            self.d_out = conf.get_int("mlp_coarse.d_out", 4)
+        else:
+            self.d_out = conf.get_int("mlp_coarse.d_out", 7) * conf.get_int("mlp_coarse.num_anchors_per_scale", 3)
+        self.d_latent = d_latent
+        self.num_objs = 0
+        self.num_views_per_obj = 1
+        # native handles (created lazily on the module's CUDA device)
+        self._h_model = None
+        self._h_scenes = []
+        self._synced_key = None
+        self._timing = False
+
+    # ---------------------------------------------------------------- native plumbing
+    def _device(self):
+        dev = self.mlp_coarse.lin_in.weight.device
+        if dev.type != "cuda":
+            raise RuntimeError("PixelNeRFNet (libpnyolo) runs on an MI355X only: move the module to a cuda device "
+                               "first (there is no CPU path)")
+        return dev
+
+    def _free_native(self):
+        L = _lib.load()
+        for s in self._h_scenes:
+            L.pny_scene_destroy(s)
+        self._h_scenes = []
+        if self._h_model is not None:
+            L.pny_model_destroy(self._h_model)
+            self._h_model = None
+
+    def __del__(self):
+        try:
+            self._free_native()
+        except Exception:
+            pass
+
+    def _weights_key(self):
+        ps = list(self.state_dict(keep_vars=True).items())
+        return (str(self._device()), self.mlp_fine is not None, tuple((k, v.data_ptr(), v._version) for k, v in ps))
+
+    def _sync(self):
+        """(Re)build the native model when parameters changed (load_weights, .to(), optimizer step)."""
+        key = self._weights_key()
+        if self._h_model is not None and key == self._synced_key:
+            return
+        L = _lib.load()
+        self._free_native()
+        dev = self._device()
+        mc = self.mlp_coarse
+        desc = ModelDesc(d_latent=self.d_latent, d_hidden=mc.d_hidden, d_out=self.d_out, n_blocks=mc.n_blocks,
+                         combine_layer=min(mc.combine_layer, 1 << 20), num_freqs=self.code.num_freqs,
+                         freq_factor=float(self.code.freq_factor), yolo=int(self.yolo),
+                         has_fine=int(self.mlp_fine is not None), device=dev.index or 0)
+        h = C.c_void_p()
+        check(L.pny_model_create(C.byref(h), C.byref(desc)))
+        self._h_model = h
+        for name, t in self.state_dict().items():
+            if name.endswith("num_batches_tracked"):
+                continue
+            a = np.ascontiguousarray(t.detach().to("cpu", torch.float32).numpy())
+            shape = (C.c_int64 * max(a.ndim, 1))(*a.shape)
+            check(L.pny_model_load_weights(h, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim))
+        check(L.pny_model_finalize(h))
+        self._synced_key = key
+
+    def _scene(self, i):
+        L = _lib.load()
+        while len(self._h_scenes) <= i:
+            s = C.c_void_p()
+            check(L.pny_scene_create(C.byref(s), self._h_model))
+            check(L.pny_scene_enable_timing(s, int(self._timing)))
+            self._h_scenes.append(s)
+        return self._h_scenes[i]
+
+    def enable_kernel_timing(self, on=True):
+        """HIP-event timing of the MLP launches (bench.py's roofline leg)."""
+        self._timing = bool(on)
+        for s in self._h_scenes:
+            check(_lib.load().pny_scene_enable_timing(s, int(on)))
+
+    def last_mlp_stats(self):
+        """(algorithmic FLOPs, kernel ms, launches) of the last call, summed over scenes."""
+        L = _lib.load()
+        fl = ms = 0.0
+        n = 0
+        for s in self._h_scenes[: max(self.num_objs, 1)]:
+            a, b, c = C.c_double(), C.c_double(), C.c_int()
+            check(L.pny_scene_last_mlp_stats(s, C.byref(a), C.byref(b), C.byref(c)))
+            fl += a.value
+            ms += b.value
+            n += c.value
+        return fl, ms, n
+
+    # ---------------------------------------------------------------- reference API
+    def encode(self, images, poses, focal, z_bounds=None, c=None, latent=None):
+        """
+        :param images (NS, 3, H, W) or (SB, NS, 3, H, W), in [-1, 1]
+        :param poses (NS, 4, 4) or (SB, NS, 4, 4) cam->world (YOLO mode: world->cam extrinsics)
+        :param focal () or (N) or (N, 2);  :param c None or () or (N) or (N, 2)
+        :param latent optional (SB*NS, L, Hl, Wl): encoder bypass (required for backbone=custom)
+        """
+        self._sync()
+        L = _lib.load()
+        dev = self._device()
+        self.num_objs = images.size(0)
+        if images.dim() == 5:
+            assert poses.dim() == 4 and poses.size(1) == images.size(1)
+            self.num_views_per_obj = images.size(1)
+            images = images.reshape(-1, *images.shape[2:])
+            poses = poses.reshape(-1, 4, 4)
+        else:
+            self.num_views_per_obj = 1
+        NS, SB = self.num_views_per_obj, self.num_objs
+        H, W = int(images.shape[-2]), int(images.shape[-1])
+        # focal / principal point formats: reference models.py:125-148
+        focal = torch.as_tensor(focal, dtype=torch.float32).cpu()
+        if focal.dim() == 0:
+            focal = focal[None, None].repeat(1, 2)
+        elif focal.dim() == 1:
+            focal = focal.unsqueeze(-1).repeat(1, 2)
+        focal = focal.contiguous()
+        if c is None:
+            c = torch.tensor([[W * 0.5, H * 0.5]], dtype=torch.float32)
+        else:
+            c = torch.as_tensor(c, dtype=torch.float32).cpu()
+            if c.dim() == 0:
+                c = c[None, None].repeat(1, 2)
+            elif c.dim() == 1:
+                c = c.unsqueeze(-1).repeat(1, 2)
+        c = c.contiguous()
+        poses_h = poses.detach().to("cpu", torch.float32).contiguous()
+        st = stream_of(dev)
+        if latent is None and self.encoder.use_custom_resnet:
+            raise RuntimeError("backbone=custom (YOLOv7) has no kernels in this build (its source and weights are "
+                               "outside the reference tree): pass the backbone output via encode(..., latent=...)")
+        if latent is not None:
+            latent = latent.detach().to(dev, torch.float32).contiguous()
+            assert latent.dim() == 4 and latent.shape[0] == SB * NS, "latent must be (SB*NS, L, Hl, Wl)"
+        else:
+            images = images.detach().to(dev, torch.float32).contiguous()
+        for sb in range(SB):
+            s = self._scene(sb)
+            # per-scene focal / c rows: batch 1 broadcasts, batch SB is per scene, batch SB*NS per view
+            def rows(t):
+                if t.shape[0] == 1:
+                    return t[:1]
+                if t.shape[0] == SB * NS:
+                    return t[sb * NS:(sb + 1) * NS]
+                if t.shape[0] == SB:
+                    return t[sb:sb + 1]
+                raise ValueError("focal / c batch must be 1, SB or SB*NS")
+            f_s, c_s = rows(focal).contiguous(), rows(c).contiguous()
+            p_s = poses_h[sb * NS:(sb + 1) * NS].contiguous()
+            check(L.pny_scene_set_cameras(s, ptr(p_s), NS, ptr(f_s), f_s.shape[0], ptr(c_s), c_s.shape[0], W, H))
+            if latent is not None:
+                lat = latent[sb * NS:(sb + 1) * NS]
+                check(L.pny_scene_set_latent(s, ptr(lat), NS, lat.shape[1], lat.shape[2], lat.shape[3], st))
+            else:
+                img = images[sb * NS:(sb + 1) * NS]
+                check(L.pny_scene_encode(s, ptr(img), NS, H, W, st))
+
+    def latent(self, sb=0):
+        """(NS, L, Hl, Wl) latent of scene `sb` as the reference keeps it in encoder.latent."""
+        L = _lib.load()
+        s = self._h_scenes[sb]
+        dims = [C.c_int() for _ in range(4)]
+        check(L.pny_scene_latent_shape(s, *[C.byref(d) for d in dims]))
+        out = torch.empty([d.value for d in dims], device=self._device(), dtype=torch.float32)
+        check(L.pny_scene_get_latent(s, ptr(out), stream_of(out.device)))
+        return out
+
+    def forward(self, xyz, coarse=True, viewdirs=None, far=False):
+        """
+        Predict (r, g, b, sigma) at world space points xyz (after encode()).
+        :param xyz (SB, B, 3);  :param viewdirs (SB, B, 3)  ->  (SB, B, d_out)
+        """
+        if torch.is_grad_enabled() and (xyz.requires_grad or self.training):
+            raise RuntimeError("libpnyolo is forward-only (SURVEY.md 8f): call it in eval() mode or under "
+                               "torch.no_grad(); gradients would silently be dropped otherwise")
+        self._sync()
+        L = _lib.load()
+        dev = self._device()
+        SB, B, _ = xyz.shape
+        assert SB == self.num_objs, "super-batch of xyz must match the encoded scenes"
+        assert viewdirs is not None, "use_viewdirs is set: viewdirs are required"
+        xyz = xyz.detach().to(dev, torch.float32).contiguous()
+        viewdirs = viewdirs.detach().to(dev, torch.float32).reshape(SB, B, 3).contiguous()
+        out = torch.empty(SB, B, self.d_out, device=dev, dtype=torch.float32)
+        use_coarse = bool(coarse) or self.mlp_fine is None
+        st = stream_of(dev)
+        for sb in range(SB):
+            check(L.pny_query(self._scene(sb), ptr(xyz[sb]), ptr(viewdirs[sb]), B, int(use_coarse), ptr(out[sb]), st))
+        return out
+
+    # ---------------------------------------------------------------- checkpoints
+    def load_weights(self, args, opt_init=False, strict=True, device=None):
+        """reference models.py:320-349: checkpoints/<name>/pixel_nerf_latest (or pixel_nerf_init)."""
+        if opt_init and not args.resume:
+            return
+        ckpt_name = "pixel_nerf_init" if opt_init else "pixel_nerf_latest"
+        model_path = "%s/%s/%s" % (args.checkpoints_path, args.name, ckpt_name)
+        if device is None:
+            device = self.mlp_coarse.lin_in.weight.device
+        if os.path.exists(model_path):
+            print("Load", model_path)
+            self.load_state_dict(torch.load(model_path, map_location=device, weights_only=True), strict=strict)
+        elif not opt_init:
+            warnings.warn("WARNING: {} does not exist, not loaded!! Model will be re-initialized.".format(model_path))
+        return self
+
+    def save_weights(self, args, opt_init=False):
+        """reference models.py:351-370"""
+        from shutil import copyfile
+        ckpt_name = "pixel_nerf_init" if opt_init else "pixel_nerf_latest"
+        backup_name = "pixel_nerf_init_backup" if opt_init else "pixel_nerf_backup"
+        ckpt_path = osp.join(args.checkpoints_path, args.name, ckpt_name)
+        ckpt_backup_path = osp.join(args.checkpoints_path, args.name, backup_name)
+        if osp.exists(ckpt_path):
+            copyfile(ckpt_path, ckpt_backup_path)
+        torch.save(self.state_dict(), ckpt_path)
+        return self
+
+
+def make_model(conf, *args, **kwargs):
+    """reference src/model/__init__.py:4-11"""
+    model_type = conf.get_string("type", "pixelnerf")
+    if model_type == "pixelnerf":
+        return PixelNeRFNet(conf, *args, **kwargs)
+    raise NotImplementedError("Unsupported model type", model_type)

@@ -1,0 +1,227 @@
+"""
+Host-side mirror of the reference's renderer layer (src/render/): ``NeRFRenderer``,
+``_RenderWrapper`` / ``bind_parallel``, ``YoloRenderer``, ``make_renderer`` with the reference's
+signatures and return conventions, executing on libpnyolo.so.
+
+A render call is ONE C-ABI call per scene (pny_render / pny_yolo_render): sampling, point
+generation, the fused MLP, compositing, importance sampling and the sort all stay on the device.
+The reference's ``eval_batch_size`` point-chunking exists only to bound its (rows x 554)
+intermediates; fusion removes them, so the attribute is kept for interface compatibility and
+ignored.
+
+Random draws: the reference jitters unconditionally (nerf.py:117) and draws three more tensors
+in the fine pass -- they are inputs of the path.  By default a per-call Philox seed is used
+(in-kernel generation); ``renderer.draws = dict(u_coarse=, u_fine=, u_fine2=, g_depth=)`` replays
+explicit tensors instead (parity mode, consumed by the next call).
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as _lib
+from .lib import RenderOpts, RenderOut, check, ptr, stream_of
+
+
+class _RenderWrapper(torch.nn.Module):
+    """reference src/render/nerf.py:21-48"""
+
+    def __init__(self, net, renderer, simple_output):
+        super().__init__()
+        self.net = net
+        self.renderer = renderer
+        self.simple_output = simple_output
+
+    def forward(self, rays, want_weights=False):
+        if rays.shape[0] == 0:
+            return (torch.zeros(0, 3, device=rays.device), torch.zeros(0, device=rays.device))
+        outputs = self.renderer(self.net, rays, want_weights=want_weights and not self.simple_output)
+        if self.simple_output:
+            part = outputs["fine"] if self.renderer.using_fine else outputs["coarse"]
+            return part["rgb"], part["depth"]
+        return outputs  # plain nested dict, as DotMap.toDict() in the reference
+
+
+class NeRFRenderer(torch.nn.Module):
+    """Drop-in for reference src/render/nerf.py:51 (ctor :68-102, forward :257-309,
+    sched_step :324-344, from_conf :346-358, bind_parallel :360-377)."""
+
+    def __init__(self, n_coarse=128, n_fine=0, n_fine_depth=0, noise_std=0.0, depth_std=0.01,
+                 eval_batch_size=100000, white_bkgd=False, lindisp=False, sched=None):
+        super().__init__()
+        self.n_coarse, self.n_fine, self.n_fine_depth = n_coarse, n_fine, n_fine_depth
+        self.noise_std, self.depth_std = noise_std, depth_std
+        self.eval_batch_size = eval_batch_size  # unused: no materialised per-point intermediates
+        self.white_bkgd = white_bkgd
+        self.lindisp = lindisp
+        if lindisp:
+            print("Using linear displacement rays")
+        self.using_fine = n_fine > 0
+        self.sched = sched
+        if sched is not None and len(sched) == 0:
+            self.sched = None
+        self.register_buffer("iter_idx", torch.tensor(0, dtype=torch.long), persistent=True)
+        self.register_buffer("last_sched", torch.tensor(0, dtype=torch.long), persistent=True)
+        self.draws = None          # explicit random draws for the next call (parity mode)
+        self.base_seed = 1234
+        self._calls = 0
+
+    def forward(self, model, rays, want_weights=False):
+        """
+        :param rays [origins (3), directions (3), near (1), far (1)] (SB, B, 8)
+        :return dict(coarse=dict(rgb (SB,B,3), depth (SB,B)[, weights (SB,B,Kc)]), fine=dict(...))
+        ``fine`` is absent when n_fine == 0 (callers test ``len(fine) > 0``, PixelNerfTrainer.py:140-143).
+        """
+        if self.sched is not None and self.last_sched.item() > 0:
+            self.n_coarse = self.sched[1][self.last_sched.item() - 1]
+            self.n_fine = self.sched[2][self.last_sched.item() - 1]
+        assert len(rays.shape) == 3
+        if self.training and self.noise_std > 0.0:
+            raise NotImplementedError("sigma noise (training only) is not part of the forward-only path")
+        if torch.is_grad_enabled() and (rays.requires_grad or model.training):
+            raise RuntimeError("libpnyolo is forward-only (SURVEY.md 8f): render in eval() mode or under no_grad()")
+        model._sync()
+        L = _lib.load()
+        dev = model._device()
+        SB, B = rays.shape[0], rays.shape[1]
+        assert SB == model.num_objs, "super-batch of rays must match the encoded scenes"
+        rays = rays.detach().to(dev, torch.float32).contiguous()
+        kc, kf, kfd = int(self.n_coarse), int(self.n_fine), int(self.n_fine_depth)
+        use_fine = self.using_fine and kf > 0
+        if not use_fine:
+            kf = kfd = 0
+        f32 = dict(device=dev, dtype=torch.float32)
+        res = {"coarse": {"rgb": torch.empty(SB, B, 3, **f32), "depth": torch.empty(SB, B, **f32)}}
+        if want_weights:
+            res["coarse"]["weights"] = torch.empty(SB, B, kc, **f32)
+        if use_fine:
+            res["fine"] = {"rgb": torch.empty(SB, B, 3, **f32), "depth": torch.empty(SB, B, **f32)}
+            if want_weights:
+                res["fine"]["weights"] = torch.empty(SB, B, kc + kf, **f32)
+        draws, self.draws = self.draws, None
+        self._calls += 1
+        st = stream_of(dev)
+        keep = []
+        for sb in range(SB):
+            o = RenderOpts(n_coarse=kc, n_fine=kf, n_fine_depth=kfd, depth_std=float(self.depth_std),
+                           white_bkgd=int(bool(self.white_bkgd)), lindisp=int(bool(self.lindisp)),
+                           seed=(self.base_seed + 7919 * self._calls + sb) & 0xFFFFFFFFFFFFFFFF)
+            if draws is not None:
+                def dev_draw(name, cols):
+                    if cols == 0:
+                        return None
+                    t = torch.as_tensor(draws[name], dtype=torch.float32).reshape(SB, B, cols)[sb].to(dev).contiguous()
+                    keep.append(t)
+                    return t.data_ptr()
+                o.u_coarse_dev = dev_draw("u_coarse", kc)
+                o.u_fine_dev = dev_draw("u_fine", kf - kfd)
+                o.u_fine2_dev = dev_draw("u_fine2", kf - kfd)
+                o.g_depth_dev = dev_draw("g_depth", kfd)
+            out = RenderOut()
+            out.rgb_coarse = res["coarse"]["rgb"][sb].data_ptr()
+            out.depth_coarse = res["coarse"]["depth"][sb].data_ptr()
+            if want_weights:
+                out.weights_coarse = res["coarse"]["weights"][sb].data_ptr()
+            if use_fine:
+                out.rgb_fine = res["fine"]["rgb"][sb].data_ptr()
+                out.depth_fine = res["fine"]["depth"][sb].data_ptr()
+                if want_weights:
+                    out.weights_fine = res["fine"]["weights"][sb].data_ptr()
+            for name, buf in (getattr(self, "_debug_out", None) or {}).items():
+                setattr(out, name, buf[sb].data_ptr())
+            check(L.pny_render(model._scene(sb), ptr(rays[sb]), B, C.byref(o), C.byref(out), st))
+        return res
+
+    def sched_step(self, steps=1):
+        """reference nerf.py:324-344"""
+        if self.sched is None:
+            return
+        self.iter_idx += steps
+        while (self.last_sched.item() < len(self.sched[0])
+               and self.iter_idx.item() >= self.sched[0][self.last_sched.item()]):
+            self.n_coarse = self.sched[1][self.last_sched.item()]
+            self.n_fine = self.sched[2][self.last_sched.item()]
+            print("INFO: NeRF sampling resolution changed on schedule ==> c", self.n_coarse, "f", self.n_fine)
+            self.last_sched += 1
+
+    @classmethod
+    def from_conf(cls, conf, white_bkgd=False, lindisp=False, eval_batch_size=100000):
+        return cls(conf.get_int("n_coarse", 128), conf.get_int("n_fine", 0),
+                   n_fine_depth=conf.get_int("n_fine_depth", 0), noise_std=conf.get_float("noise_std", 0.0),
+                   depth_std=conf.get_float("depth_std", 0.01), white_bkgd=conf.get_float("white_bkgd", white_bkgd),
+                   lindisp=lindisp, eval_batch_size=conf.get_int("eval_batch_size", eval_batch_size),
+                   sched=conf.get_list("sched", None))
+
+    def bind_parallel(self, net, gpus=None, simple_output=False):
+        """reference nerf.py:360-377.  The reference wraps the module in a single-process
+        ``DataParallel(dim=1)`` that re-broadcasts all parameters and the latent on every call;
+        here multi-GPU is one process per GPU (dist.py: ray sharding + one RCCL all-gather), so a
+        `gpus` list longer than one is refused rather than silently run on one device."""
+        if gpus is not None and len(gpus) > 1:
+            raise NotImplementedError(
+                "multi-GPU rendering is one process per GPU in this framework: launch with "
+                "torch.distributed.run and use pixel_nerf_yolo_amd.dist.render_sharded (see INTEGRATION.md)")
+        return _RenderWrapper(net, self, simple_output=simple_output)
+
+
+class YoloRenderer(torch.nn.Module):
+    """Drop-in for reference src/render/yolo.py:3 (forward :37-114, from_conf :28-35,
+    bind_parallel :116-121)."""
+
+    def __init__(self, n_coarse, eval_batch_size, num_scales, num_anchors_per_scale):
+        super().__init__()
+        self.net = None
+        self.n_coarse = n_coarse
+        self.eval_batch_size = eval_batch_size  # unused (see module docstring)
+        self.num_scales = num_scales
+        self.num_anchors_per_scale = num_anchors_per_scale
+        self.draws = None
+        self.base_seed = 4321
+        self._calls = 0
+
+    def bind_net(self, net):
+        self.net = net
+
+    @classmethod
+    def from_conf(cls, conf):
+        return cls(conf.get_int("renderer.n_coarse", 128), conf.get_int("renderer.eval_batch_size", 1024),
+                   conf.get_int("model.mlp_coarse.num_scales", 1),
+                   conf.get_int("model.mlp_coarse.num_anchors_per_scale", 3))
+
+    def forward(self, rays):
+        """rays (..., 8) flattened to (N, 8) as the reference does (SB is folded away: only SB=1
+        is meaningful, yolo.py:38,81) -> (N, num_anchors_per_scale, 7)."""
+        net = self.net
+        if torch.is_grad_enabled() and (rays.requires_grad or net.training):
+            raise RuntimeError("libpnyolo is forward-only (SURVEY.md 8f): render in eval() mode or under no_grad()")
+        net._sync()
+        L = _lib.load()
+        dev = net._device()
+        rays = rays.detach().to(dev, torch.float32).reshape(-1, 8).contiguous()
+        n = rays.shape[0]
+        out = torch.empty(n, self.num_anchors_per_scale, 7, device=dev, dtype=torch.float32)
+        draws, self.draws = self.draws, None
+        self._calls += 1
+        u = None
+        if draws is not None:
+            u = torch.as_tensor(draws["u_coarse"], dtype=torch.float32).reshape(n, self.n_coarse).to(dev).contiguous()
+        raw = getattr(self, "_debug_raw", None)
+        check(L.pny_yolo_render(net._scene(0), ptr(rays), n, int(self.n_coarse), ptr(u),
+                                (self.base_seed + 7919 * self._calls) & 0xFFFFFFFFFFFFFFFF, ptr(out), ptr(raw),
+                                stream_of(dev)))
+        return out
+
+    def bind_parallel(self, net, gpus=None):
+        self.net = net
+        if gpus is not None and len(gpus) > 1:
+            raise NotImplementedError("multi-GPU: one process per GPU (pixel_nerf_yolo_amd.dist), not DataParallel")
+        return self
+
+
+def make_renderer(conf, lindisp=False):
+    """reference src/render/render_util.py:5-12"""
+    renderer_type = conf.get_string("renderer.type", "nerf")
+    if renderer_type == "nerf":
+        return NeRFRenderer.from_conf(conf["renderer"], lindisp=lindisp)
+    if renderer_type == "yolo":
+        return YoloRenderer.from_conf(conf)
+    raise NotImplementedError("Unsupported renderer type")

@@ -1,0 +1,187 @@
+"""
+CPU-side checks (no GPU): the C-ABI library loads and exports every symbol include/pnyolo.h
+declares, the host mirrors expose the reference's interface (names, state_dict keys, config
+defaults), errors are loud without a GPU, and the multi-process sharding logic works over gloo.
+"""
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from pixel_nerf_yolo_amd import conf as pconf
+from pixel_nerf_yolo_amd import dist as pdist
+from pixel_nerf_yolo_amd import lib as plib
+from pixel_nerf_yolo_amd import synth
+from pixel_nerf_yolo_amd.model import PixelNeRFNet, make_model
+from pixel_nerf_yolo_amd.render import NeRFRenderer, YoloRenderer, make_renderer
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    if not os.path.exists(plib.LIB_PATH):
+        plib.build()
+    return plib.load()
+
+
+def test_abi_exports_every_declared_symbol(built_lib):
+    hdr = open(os.path.join(ROOT, "include", "pnyolo.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(pny_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    assert declared == set(plib.SIGNATURES.keys()), declared ^ set(plib.SIGNATURES.keys())
+    for name in declared:
+        assert hasattr(built_lib, name)
+    assert built_lib.pny_version() == 1
+
+
+def test_no_gpu_is_loud(built_lib):
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import ctypes as C
+    h = C.c_void_p()
+    desc = plib.ModelDesc(d_latent=512, d_hidden=512, d_out=4, n_blocks=5, combine_layer=3, num_freqs=6,
+                          freq_factor=1.5, yolo=0, has_fine=1, device=0)
+    rc = built_lib.pny_model_create(C.byref(h), C.byref(desc))
+    assert rc == -4 and b"no HIP device" in built_lib.pny_last_error()
+    with pytest.raises(plib.PnyError):
+        plib.check(rc)
+    net = make_model(pconf.default_mv()["model"]).eval()
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        net.encode(torch.zeros(1, 1, 3, 64, 64), torch.eye(4)[None, None], torch.tensor(60.0))
+
+
+def test_desc_validation(built_lib):
+    import ctypes as C
+    h = C.c_void_p()
+    bad = plib.ModelDesc(d_latent=512, d_hidden=256, d_out=4, n_blocks=5, combine_layer=3, num_freqs=6,
+                         freq_factor=1.5, yolo=0, has_fine=1, device=0)
+    assert built_lib.pny_model_create(C.byref(h), C.byref(bad)) == -1
+    assert b"d_hidden" in built_lib.pny_last_error()
+    bad2 = plib.ModelDesc(d_latent=500, d_hidden=512, d_out=4, n_blocks=5, combine_layer=3, num_freqs=6,
+                          freq_factor=1.5, yolo=0, has_fine=1, device=0)
+    assert built_lib.pny_model_create(C.byref(h), C.byref(bad2)) == -1
+    assert built_lib.pny_model_create(None, None) == -1
+
+
+def test_state_dict_keys_match_reference_checkpoint_layout():
+    """names/shapes a `pixel_nerf_latest` checkpoint holds."""
+    net = make_model(pconf.default_mv()["model"])
+    sd = net.state_dict()
+    for mlp in ("mlp_coarse", "mlp_fine"):
+        assert tuple(sd[mlp + ".lin_in.weight"].shape) == (512, 42)
+        for i in range(3):
+            assert tuple(sd["%s.lin_z.%d.weight" % (mlp, i)].shape) == (512, 512)
+        for i in range(5):
+            for fc in ("fc_0", "fc_1"):
+                assert tuple(sd["%s.blocks.%d.%s.weight" % (mlp, i, fc)].shape) == (512, 512)
+        assert tuple(sd[mlp + ".lin_out.weight"].shape) == (4, 512)
+        assert sum(v.numel() for k, v in sd.items() if k.startswith(mlp + ".")) == 3438596
+    assert tuple(sd["code._freqs"].shape) == (1, 12, 1) and tuple(sd["code._phases"].shape) == (1, 12, 1)
+    assert tuple(sd["encoder.model.conv1.weight"].shape) == (64, 3, 7, 7)
+    assert "encoder.model.layer4.2.bn2.running_var" in sd and "encoder.model.bn1.num_batches_tracked" in sd
+    assert "encoder.model.layer2.0.downsample.1.running_mean" in sd
+    assert not any(k.startswith("encoder.model.fc") for k in sd)
+    # our synthetic generators produce loadable state
+    miss = net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.resnet34_state(1).items()}, strict=False)
+    assert not miss.unexpected_keys
+    net.mlp_coarse.load_state_dict({k: torch.from_numpy(v) for k, v in synth.mlp_state(2).items()}, strict=True)
+    # reference init: fc_1 weights and all biases zero (resnetfc.py:36-39)
+    fresh = make_model(pconf.default_mv()["model"])
+    assert float(fresh.mlp_coarse.blocks[0].fc_1.weight.abs().max()) == 0.0
+    assert float(fresh.mlp_coarse.lin_in.bias.abs().max()) == 0.0
+
+
+def test_yolo_conf_model_and_renderer():
+    c = pconf.yolo()
+    net = make_model(c["model"])
+    assert net.yolo and net.d_out == 21 and net.mlp_fine is None and net.d_latent == 1792
+    assert tuple(net.state_dict()["mlp_coarse.lin_z.0.weight"].shape) == (512, 1792)
+    assert sum(p.numel() for p in net.mlp_coarse.parameters()) == 5413397
+    ren = make_renderer(c)
+    assert isinstance(ren, YoloRenderer) and ren.n_coarse == 128 and ren.eval_batch_size == 128
+    assert ren.num_anchors_per_scale == 3
+    assert isinstance(make_renderer(pconf.default_mv()), NeRFRenderer)
+
+
+def test_renderer_interface_and_sched():
+    ren = NeRFRenderer.from_conf(pconf.default_mv()["renderer"], lindisp=False, eval_batch_size=50000)
+    assert (ren.n_coarse, ren.n_fine, ren.n_fine_depth, ren.using_fine, ren.eval_batch_size) == (64, 32, 16, True, 50000)
+    assert ren.white_bkgd and ren.sched is None
+    assert set(ren.state_dict().keys()) == {"iter_idx", "last_sched"}
+    ren2 = NeRFRenderer(n_coarse=16, n_fine=0, sched=[[2, 4], [32, 64], [8, 16]])
+    ren2.sched_step(3)
+    assert (ren2.n_coarse, ren2.n_fine, int(ren2.last_sched)) == (32, 8, 1)
+    ren2.sched_step(1)
+    assert (ren2.n_coarse, ren2.n_fine, int(ren2.last_sched)) == (64, 16, 2)
+    # eval scripts mutate these attributes (eval.py:142-148 of the reference)
+    ren.n_coarse, ren.n_fine, ren.using_fine = 128, 0, False
+
+
+def test_unsupported_configs_are_refused():
+    c = pconf.default_mv()
+    c.d["model"]["mlp_coarse"]["use_spade"] = True
+    with pytest.raises(NotImplementedError):
+        make_model(c["model"])
+    c = pconf.default_mv()
+    c.d["model"]["encoder"]["index_padding"] = "border"
+    with pytest.raises(NotImplementedError):
+        make_model(c["model"])
+    c = pconf.default_mv()
+    c.d["model"]["use_code_viewdirs"] = True
+    with pytest.raises(NotImplementedError):
+        make_model(c["model"])
+
+
+def test_shard_bounds_cover_exactly():
+    for n in (0, 1, 63, 64, 16384, 160000, 12345):
+        for world in (1, 2, 4, 8):
+            spans = [pdist.shard_bounds(n, world, r) for r in range(world)]
+            per = spans[0][2]
+            assert per % 64 == 0 and per * world >= n
+            covered = sum(hi - lo for lo, hi, _ in spans)
+            assert covered == n
+            for r, (lo, hi, _) in enumerate(spans):
+                assert lo == min(n, r * per) and lo <= hi <= n
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("n", [1000, 50])
+def test_render_sharded_gloo_world2(n):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    import dist_worker
+    procs = [ctx.Process(target=dist_worker.run, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True, (n, 3)), (1, True, (n, 3))]
+
+
+def test_bench_json_contract_fields():
+    import json
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--describe"], capture_output=True, text=True,
+                         timeout=120)
+    assert out.returncode == 0, out.stderr
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    for k in ("metric", "unit", "config", "flop_per_ray"):
+        assert k in d
+    assert d["unit"] == "rays/s" and d["config"]["workload"].startswith("C2")
+    assert abs(d["flop_per_ray"] - 2.6218e9) / 2.6218e9 < 1e-3

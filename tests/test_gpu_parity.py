@@ -1,0 +1,330 @@
+"""
+Parity tests proper (-m gpu, real MI355X): the HIP path, called through the C ABI, against
+  (1) golden vectors captured from the reference itself (tests/golden/*.npz), and
+  (2) the oracle on the same seeded inputs,
+plus size-independent properties at BASELINE.json's full frame size.
+
+Tolerances (fp32; north_star: RGB/sigma within 1e-4 of the reference's PyTorch path on identical
+rays and identical random draws):
+  * per-sample rgb (sigmoid, in [0,1]) and sigma: 1e-4 absolute
+  * composited rgb / depth / weights: 1e-4 absolute (observed ~1e-6)
+  * bit-exact where the arithmetic is order-free (coarse depths, sort)
+Importance sampling is discontinuous in the coarse weights (searchsorted on a cdf): an fp32-ulp
+difference upstream can move ONE fine sample to the neighbouring bin (hard part 5).
+Fine-pass checks therefore allow a bounded number of such rays and verify that every deviating
+ray really is a near-edge case.
+"""
+import numpy as np
+import pytest
+import torch
+
+import pnyolo_oracle as orc
+from helpers import load_mlp, maxabs, nerf_net, oracle_scene
+from pixel_nerf_yolo_amd import conf as pconf
+from pixel_nerf_yolo_amd import lib as plib
+from pixel_nerf_yolo_amd import synth
+from pixel_nerf_yolo_amd.model import make_model
+from pixel_nerf_yolo_amd.render import NeRFRenderer, YoloRenderer, make_renderer
+from pixel_nerf_yolo_amd.util import gen_rays, gen_rays_yolo
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-4
+
+
+def dt(x):
+    return torch.as_tensor(np.asarray(x), dtype=torch.float32, device=DEV).contiguous()
+
+
+def render_debug(ren, net, rays, draws, kc, kt):
+    """Render with explicit draws and capture the per-sample / z buffers through the ABI."""
+    n = rays.shape[0]
+    dbg = {"z_coarse": torch.empty(1, n, kc, device=DEV), "sample_coarse": torch.empty(1, n, kc, 4, device=DEV)}
+    if kt > kc:
+        dbg["z_fine"] = torch.empty(1, n, kt, device=DEV)
+        dbg["sample_fine"] = torch.empty(1, n, kt, 4, device=DEV)
+    ren._debug_out = dbg
+    ren.draws = draws
+    with torch.no_grad():
+        out = ren(net, dt(rays)[None], want_weights=True)
+    torch.cuda.synchronize()
+    ren._debug_out = None
+    return out, dbg
+
+
+# --------------------------------------------------------------------------- golden: rays
+def test_gen_rays_golden(golden):
+    g = golden("rays")
+    poses = dt(g["poses"])
+    r1 = gen_rays(poses, 20, 12, torch.tensor(35.5), 0.8, 1.8, c=None)
+    r2 = gen_rays(poses[:1], 16, 16, torch.tensor([30.0, 28.0]), 0.5, 2.5, c=torch.tensor([7.5, 9.25]))
+    assert r1.shape == g["r1"].shape and maxabs(r1, g["r1"]) < 1e-6
+    assert maxabs(r2, g["r2"]) < 1e-6
+    r3 = gen_rays_yolo(dt(g["w2c"]), 48, 27, g["yolo_focal"], g["yolo_c"], 5.0, 10.0)
+    assert r3.shape == g["r3"].shape and maxabs(r3, g["r3"]) < 1e-5
+
+
+# --------------------------------------------------------------------------- golden: model
+@pytest.mark.parametrize("name,seed", [("nerf_c1", 1), ("nerf_c2", 7)])
+def test_query_golden(golden, name, seed):
+    g = golden(name)
+    net = nerf_net(g, seed)
+    xyz, vd = dt(g["probe_xyz"])[None], dt(g["probe_viewdirs"])[None]
+    with torch.no_grad():
+        out_c = net(xyz, coarse=True, viewdirs=vd)[0]
+    assert maxabs(out_c, g["probe_out_coarse"]) < TOL
+    if "probe_out_fine" in g:
+        with torch.no_grad():
+            out_f = net(xyz, coarse=False, viewdirs=vd)[0]
+        assert maxabs(out_f, g["probe_out_fine"]) < TOL
+        # eval.py:140 of the reference: net.mlp_fine = None -> the fine pass uses the coarse MLP
+        net.mlp_fine = None
+        with torch.no_grad():
+            out_f2 = net(xyz, coarse=False, viewdirs=vd)[0]
+        assert maxabs(out_f2, g["probe_out_coarse"]) < TOL
+
+
+# --------------------------------------------------------------------------- golden: render
+def test_render_c1_golden(golden):
+    g = golden("nerf_c1")
+    net = nerf_net(g, 1)
+    ren = NeRFRenderer(n_coarse=32, n_fine=0, white_bkgd=True).eval()
+    out, dbg = render_debug(ren, net, g["rays"], dict(u_coarse=g["u_coarse"]), 32, 32)
+    assert "fine" not in out
+    assert maxabs(dbg["z_coarse"][0], g["z_coarse"]) == 0.0
+    assert maxabs(dbg["sample_coarse"][0].reshape(-1, 4), g["coarse_out"]) < TOL
+    assert maxabs(out["coarse"]["weights"][0], g["coarse_weights"]) < TOL
+    assert maxabs(out["coarse"]["rgb"][0], g["coarse_rgb"]) < TOL
+    assert maxabs(out["coarse"]["depth"][0], g["coarse_depth"]) < TOL
+
+
+def fine_flip_report(z_hip, z_ref, rays, weights_ref, u_fine, kc):
+    """Rays whose sorted fine depths differ; each must be explained by a cdf-edge tie."""
+    bad = ((z_hip - z_ref).abs().max(dim=1)[0] > 1e-6).nonzero().flatten().tolist()
+    w = weights_ref + 1e-5
+    cdf = torch.cumsum(w / w.sum(-1, keepdim=True), -1)
+    for r in bad:
+        margin = (cdf[r][None, :] - torch.as_tensor(u_fine[r])[:, None]).abs().min()
+        assert float(margin) < 1e-5, "ray %d differs without a near-edge draw (margin %.2e)" % (r, float(margin))
+    return bad
+
+
+def test_render_c2_golden(golden):
+    g = golden("nerf_c2")
+    net = nerf_net(g, 7)
+    ren = NeRFRenderer(n_coarse=64, n_fine=32, n_fine_depth=16, depth_std=0.01, white_bkgd=True).eval()
+    draws = {k: g[k] for k in ("u_coarse", "u_fine", "u_fine2", "g_depth")}
+    out, dbg = render_debug(ren, net, g["rays"], draws, 64, 96)
+    n = g["rays"].shape[0]
+    assert maxabs(dbg["z_coarse"][0], g["z_coarse"]) == 0.0
+    assert maxabs(dbg["sample_coarse"][0].reshape(-1, 4), g["coarse_out"]) < TOL
+    assert maxabs(out["coarse"]["rgb"][0], g["coarse_rgb"]) < TOL
+    assert maxabs(out["coarse"]["depth"][0], g["coarse_depth"]) < TOL
+    assert maxabs(out["coarse"]["weights"][0], g["coarse_weights"]) < TOL
+    # fine pass: reference's sorted depths re-derived by the oracle from the golden coarse pass
+    rays = torch.from_numpy(g["rays"])
+    zf = orc.sample_fine(rays, torch.from_numpy(g["coarse_weights"]), g["u_fine"], g["u_fine2"], 64)
+    zd = orc.sample_fine_depth(rays, torch.from_numpy(g["coarse_depth"]), g["g_depth"], 0.01)
+    z_ref, _ = torch.sort(torch.cat([torch.from_numpy(g["z_coarse"]), zf, zd], -1), -1)
+    z_hip = dbg["z_fine"][0].cpu()
+    bad = fine_flip_report(z_hip, z_ref, rays, torch.from_numpy(g["coarse_weights"]), g["u_fine"], 64)
+    assert len(bad) <= 2
+    good = torch.ones(n, dtype=torch.bool)
+    good[bad] = False
+    assert maxabs(dbg["sample_fine"][0].cpu()[good].reshape(-1, 4), g["fine_out"].reshape(n, 96, 4)[good].reshape(-1, 4)) < TOL
+    assert maxabs(out["fine"]["rgb"][0].cpu()[good], g["fine_rgb"][good]) < TOL
+    assert maxabs(out["fine"]["depth"][0].cpu()[good], g["fine_depth"][good]) < TOL
+    assert maxabs(out["fine"]["weights"][0].cpu()[good], g["fine_weights"][good]) < TOL
+    # a moved sample changes the quadrature, not the scene: still close
+    assert maxabs(out["fine"]["rgb"][0], g["fine_rgb"]) < 2e-2
+
+
+def test_simple_output_and_wrapper(golden):
+    g = golden("nerf_c2")
+    net = nerf_net(g, 7)
+    c = pconf.default_mv()
+    ren = make_renderer(c).eval()
+    assert isinstance(ren, NeRFRenderer) and ren.n_coarse == 64 and ren.n_fine == 32 and ren.using_fine
+    par = ren.bind_parallel(net, [0], simple_output=True).eval()
+    ren.draws = {k: g[k] for k in ("u_coarse", "u_fine", "u_fine2", "g_depth")}
+    with torch.no_grad():
+        rgb, depth = par(dt(g["rays"])[None])
+    assert rgb.shape == (1, 100, 3) and depth.shape == (1, 100)
+    assert float((rgb[0].cpu() - torch.from_numpy(g["fine_rgb"])).abs().median()) < 1e-5
+    # empty-ray guard of _RenderWrapper (reference nerf.py:29-33)
+    e_rgb, e_d = par(torch.zeros(0, 5, 8, device=DEV))
+    assert e_rgb.shape == (0, 3) and e_d.shape == (0,)
+    # full dict output, no weights requested
+    par2 = ren.bind_parallel(net, None, simple_output=False)
+    with torch.no_grad():
+        d = par2(dt(g["rays"])[None])
+    assert set(d.keys()) == {"coarse", "fine"} and set(d["fine"].keys()) == {"rgb", "depth"}
+    with pytest.raises(NotImplementedError):
+        ren.bind_parallel(net, [0, 1])
+
+
+# --------------------------------------------------------------------------- stages via the ABI
+def test_stage_kernels_vs_golden(golden):
+    g = golden("nerf_c2")
+    L = plib.load()
+    st = plib.stream_of(torch.device(DEV))
+    n = 100
+    rays = dt(g["rays"])
+    z = torch.empty(n, 64, device=DEV)
+    plib.check(L.pny_sample_coarse(plib.ptr(rays), n, 64, 0, plib.ptr(dt(g["u_coarse"])), 0, plib.ptr(z), st))
+    assert maxabs(z, g["z_coarse"]) == 0.0
+    w, rgb, dep = torch.empty(n, 64, device=DEV), torch.empty(n, 3, device=DEV), torch.empty(n, device=DEV)
+    plib.check(L.pny_composite(plib.ptr(rays), plib.ptr(dt(g["z_coarse"])), plib.ptr(dt(g["coarse_out"])), n, 64, 1,
+                               plib.ptr(w), plib.ptr(rgb), plib.ptr(dep), st))
+    assert maxabs(w, g["coarse_weights"]) < 2e-6
+    assert maxabs(rgb, g["coarse_rgb"]) < 2e-6 and maxabs(dep, g["coarse_depth"]) < 2e-6
+    # fine sampling + sort on the reference's own coarse weights: same bins, same depths
+    zo = torch.empty(n, 96, device=DEV)
+    plib.check(L.pny_sample_fine(plib.ptr(rays), plib.ptr(dt(g["z_coarse"])), plib.ptr(dt(g["coarse_weights"])),
+                                 plib.ptr(dt(g["coarse_depth"])), n, 64, 32, 16, 0.01, 0, plib.ptr(dt(g["u_fine"])),
+                                 plib.ptr(dt(g["u_fine2"])), plib.ptr(dt(g["g_depth"])), 0, plib.ptr(zo), st))
+    r = torch.from_numpy(g["rays"])
+    zf = orc.sample_fine(r, torch.from_numpy(g["coarse_weights"]), g["u_fine"], g["u_fine2"], 64)
+    zd = orc.sample_fine_depth(r, torch.from_numpy(g["coarse_depth"]), g["g_depth"], 0.01)
+    z_ref, _ = torch.sort(torch.cat([torch.from_numpy(g["z_coarse"]), zf, zd], -1), -1)
+    bad = fine_flip_report(zo.cpu(), z_ref, r, torch.from_numpy(g["coarse_weights"]), g["u_fine"], 64)
+    assert len(bad) <= 1
+    assert bool((zo[:, 1:] >= zo[:, :-1]).all())
+    # composite of the fine pass on golden inputs (K = 96 > one wavefront: carried transmittance)
+    w2, rgb2 = torch.empty(n, 96, device=DEV), torch.empty(n, 3, device=DEV)
+    plib.check(L.pny_composite(plib.ptr(rays), plib.ptr(dt(z_ref)), plib.ptr(dt(g["fine_out"])), n, 96, 1,
+                               plib.ptr(w2), plib.ptr(rgb2), None, st))
+    assert maxabs(w2, g["fine_weights"]) < 2e-6 and maxabs(rgb2, g["fine_rgb"]) < 2e-6
+
+
+# --------------------------------------------------------------------------- YOLO mode
+def yolo_net(g):
+    net = make_model(pconf.yolo()["model"]).eval()
+    load_mlp(net.mlp_coarse, 31, 1792, 21)
+    net = net.to(DEV)
+    lat = torch.from_numpy(synth.latent(33, 3, 1792, 16, 16))
+    net.encode(torch.zeros(1, 3, 3, 128, 128), torch.from_numpy(g["src_w2c"])[None],
+               torch.from_numpy(g["focal"])[None], c=torch.from_numpy(g["c"])[None], latent=lat)
+    return net
+
+
+def test_yolo_render_golden(golden):
+    g = golden("yolo_c3")
+    net = yolo_net(g)
+    assert net.d_out == 21 and net.mlp_fine is None
+    ren = make_renderer(pconf.yolo())
+    assert isinstance(ren, YoloRenderer) and ren.n_coarse == 128
+    par = ren.bind_parallel(net)
+    n = g["rays"].shape[0]
+    ren._debug_raw = torch.empty(n, 128, 21, device=DEV)
+    ren.draws = dict(u_coarse=g["u_coarse"])
+    with torch.no_grad():
+        out = par(dt(g["rays"])[None])
+    torch.cuda.synchronize()
+    scale = max(1.0, float(np.abs(g["raw_out"]).max()))
+    assert maxabs(ren._debug_raw.reshape(-1, 21), g["raw_out"]) < TOL * scale
+    assert out.shape == (n, 3, 7) and maxabs(out, g["yolo_out"]) < TOL * scale
+    rays_all = gen_rays_yolo(dt(g["tgt_w2c"])[None], int(g["Wc"]), int(g["Hc"]), g["focal"] / 8, g["c"] / 8, 1.0, 13.0)
+    assert maxabs(rays_all[0], g["rays_all"]) < 1e-5
+    # backbone=custom without a supplied latent must fail loudly (no silent fallback)
+    with pytest.raises(RuntimeError):
+        net.encode(torch.zeros(1, 3, 3, 128, 128), torch.from_numpy(g["src_w2c"])[None], torch.from_numpy(g["focal"])[None])
+
+
+# --------------------------------------------------------------------------- encoder
+def test_encoder_golden(golden):
+    g = golden("encoder")
+    net = make_model(pconf.default_mv()["model"]).eval()
+    sd = synth.resnet34_state(45, prefix="encoder.model.")
+    missing = net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert not missing.unexpected_keys
+    net = net.to(DEV)
+    ns, H, W = int(g["NS"]), int(g["H"]), int(g["W"])
+    img = torch.from_numpy(synth.images(46, ns, H, W))
+    src, _ = synth.scene_cameras(ns)
+    net.encode(img[None], torch.from_numpy(src)[None], torch.tensor(60.0))
+    lat = net.latent(0)
+    assert lat.shape == g["latent"].shape
+    scale = float(np.abs(g["latent"]).max())
+    assert maxabs(lat, g["latent"]) < 2e-5 * scale  # random-weight trunk: activations reach O(100)
+
+
+# --------------------------------------------------------------------------- oracle, ragged sizes
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 257])
+def test_query_ragged_vs_oracle(golden, n):
+    g = golden("nerf_c2")
+    net = nerf_net(g, 7)
+    sc = oracle_scene(g, 7)
+    rs = np.random.RandomState(n)
+    xyz = rs.uniform(-0.5, 0.5, size=(n, 3)).astype(np.float32)
+    vd = rs.standard_normal((n, 3)).astype(np.float32)
+    with torch.no_grad():
+        out = net(dt(xyz)[None], coarse=False, viewdirs=dt(vd)[None])[0]
+    ref = orc.query(sc, xyz, vd, coarse=False)
+    assert out.shape == (n, 4) and maxabs(out, ref) < TOL
+
+
+def test_forward_only_is_loud(golden):
+    g = golden("nerf_c1")
+    net = nerf_net(g, 1)
+    net.train()
+    with pytest.raises(RuntimeError):
+        net(dt(g["probe_xyz"])[None], viewdirs=dt(g["probe_viewdirs"])[None])
+    with pytest.raises(RuntimeError):
+        make_model(pconf.default_mv()["model"]).eval()(torch.zeros(1, 4, 3), viewdirs=torch.zeros(1, 4, 3))  # CPU module
+
+
+# --------------------------------------------------------------------------- full-size properties
+def test_full_frame_properties():
+    """BASELINE config 2 size (128x128, 3 views, 64+32): properties that need no oracle run."""
+    NS, H, W = 3, 128, 128
+    net = make_model(pconf.default_mv()["model"]).eval()
+    load_mlp(net.mlp_coarse, 71, 512, 4)
+    load_mlp(net.mlp_fine, 72, 512, 4)
+    net = net.to(DEV)
+    src, tgt = synth.scene_cameras(NS)
+    lat = torch.from_numpy(synth.latent(73, NS, 512, H // 2, W // 2))
+    focal, c = torch.tensor(131.25), torch.tensor([[64.0, 64.0]])
+    net.encode(torch.zeros(1, NS, 3, H, W), torch.from_numpy(src)[None], focal, c=c, latent=lat)
+    rays = gen_rays(dt(tgt)[None], W, H, focal, 0.8, 1.8, c=c[0]).reshape(1, -1, 8)
+    ren = NeRFRenderer(n_coarse=64, n_fine=32, n_fine_depth=16, white_bkgd=True).eval()
+    n = rays.shape[1]
+    dbg = {"z_fine": torch.empty(1, n, 96, device=DEV), "z_coarse": torch.empty(1, n, 64, device=DEV)}
+    ren._debug_out = dbg
+    ren.base_seed, ren._calls = 99, 0
+    with torch.no_grad():
+        a = ren(net, rays, want_weights=True)
+    ren._calls = 0
+    with torch.no_grad():
+        b = ren(net, rays, want_weights=True)
+    torch.cuda.synchronize()
+    # determinism / idempotence: same seed, same frame, bit for bit
+    assert torch.equal(a["fine"]["rgb"], b["fine"]["rgb"]) and torch.equal(a["fine"]["weights"], b["fine"]["weights"])
+    zf, zc = dbg["z_fine"][0], dbg["z_coarse"][0]
+    assert bool((zf[:, 1:] >= zf[:, :-1]).all())                      # sortedness
+    assert bool((zc >= 0.8).all() and (zc <= 1.8).all())
+    step = (1.8 - 0.8) / 64                                           # one coarse sample per stratum
+    k = torch.arange(64, device=DEV)
+    assert bool((zc >= 0.8 + k * step - 1e-5).all() and (zc <= 0.8 + (k + 1) * step + 1e-5).all())
+    for part in ("coarse", "fine"):
+        w = a[part]["weights"][0]
+        assert bool(torch.isfinite(w).all()) and bool((w >= 0).all())
+        assert float(w.sum(-1).max()) <= 1.0 + 1e-4                   # weights form a sub-partition of unity
+        rgb = a[part]["rgb"][0]
+        assert float(rgb.min()) >= -1e-5 and float(rgb.max()) <= 1.0 + 1e-4   # white bkgd keeps rgb in [0,1]
+        d = a[part]["depth"][0]
+        assert float(d.min()) >= 0.0 and float(d.max()) <= 1.8 + 1e-4
+    # a contiguous slice of the frame renders to the same pixels (ray independence -> sharding)
+    ren._debug_out = None
+    sub = rays[:, 5000:5200].contiguous()
+    draws = dict(u_coarse=torch.rand(200, 64), u_fine=torch.rand(200, 16), u_fine2=torch.rand(200, 16),
+                 g_depth=torch.randn(200, 16))
+    ren.draws = draws
+    with torch.no_grad():
+        s1 = ren(net, sub)
+    pad = torch.cat([rays[:, :37], sub, rays[:, 9000:9100]], 1).contiguous()
+    ren.draws = {k2: torch.cat([torch.rand(37, v.shape[1]), v, torch.rand(100, v.shape[1])], 0) if k2 != "g_depth"
+                 else torch.cat([torch.randn(37, 16), v, torch.randn(100, 16)], 0) for k2, v in draws.items()}
+    with torch.no_grad():
+        s2 = ren(net, pad)
+    assert torch.equal(s1["fine"]["rgb"][0], s2["fine"]["rgb"][0, 37:237])
