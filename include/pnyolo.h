@@ -73,8 +73,12 @@ void pny_model_destroy(pny_model* m);
 int pny_model_load_weights(pny_model* m, const char* name, const float* data_host,
                            const int64_t* shape, int ndim);
 /* Packs the loaded tensors into the MFMA operand order and uploads them.  Fails with
- * PNY_ERR_STATE and names the first missing MLP tensor.  Synchronous. */
+ * PNY_ERR_STATE and names the first missing MLP tensor.  Synchronous.  May be called again after
+ * further pny_model_load_weights calls (weights changed); scenes of the model stay valid. */
 int pny_model_finalize(pny_model* m);
+/* `net.mlp_fine = None` (reference eval/eval.py:140): with enable=0 the fine pass of pny_render and
+ * pny_query(coarse=0) evaluate mlp_coarse.  Default 1 (ignored when the model has no fine MLP). */
+int pny_model_use_fine(pny_model* m, int enable);
 
 int pny_scene_create(pny_scene** out, pny_model* m);
 void pny_scene_destroy(pny_scene* s);

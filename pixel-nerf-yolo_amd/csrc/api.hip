@@ -58,6 +58,7 @@ struct pny_model {
     pny_model_desc desc;
     std::map<std::string, HostTensor> host;  // state_dict tensors as loaded
     bool finalized = false;
+    bool use_fine = true;
     DevBuf packed;                            // all MLP weights, one allocation
     MlpWeights coarse{}, fine{};
     EncoderWeights enc;                       // folded conv+bn (encoder.h)
@@ -212,6 +213,7 @@ int pny_model_finalize(pny_model* m) {
     PNY_HIP(hipSetDevice(m->desc.device));
     PackPlan plan;
     int rc;
+    PNY_HIP(hipDeviceSynchronize());  // a re-finalize must not overwrite weights a running kernel reads
     if ((rc = pack_mlp(m, "mlp_coarse.", m->coarse, plan))) return rc;
     if (m->desc.has_fine && (rc = pack_mlp(m, "mlp_fine.", m->fine, plan))) return rc;
     if ((rc = m->packed.reserve(plan.blob.size() * sizeof(float)))) return rc;
@@ -233,6 +235,12 @@ int pny_model_finalize(pny_model* m) {
         m->has_encoder = true;
     }
     m->finalized = true;
+    return PNY_OK;
+}
+
+int pny_model_use_fine(pny_model* m, int enable) {
+    if (!m) return fail(PNY_ERR_ARG, "pny_model_use_fine: null model");
+    m->use_fine = enable != 0;
     return PNY_OK;
 }
 
@@ -458,7 +466,7 @@ static int run_mlp(pny_scene* s, int mode, const float* xyz, const float* dirs, 
     const pny_model_desc& d = s->m->desc;
     MlpArgs a;
     memset(&a, 0, sizeof(a));
-    a.w = (coarse || !d.has_fine) ? s->m->coarse : s->m->fine;
+    a.w = (coarse || !d.has_fine || !s->m->use_fine) ? s->m->coarse : s->m->fine;
     a.latent = s->latent.f();
     a.cams = reinterpret_cast<const Cam*>(s->cams.p);
     a.xyz = xyz;

@@ -48,6 +48,7 @@ SIGNATURES = {
     "pny_model_destroy": (None, [C.c_void_p]),
     "pny_model_load_weights": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, c_i64_p, C.c_int]),
     "pny_model_finalize": (C.c_int, [C.c_void_p]),
+    "pny_model_use_fine": (C.c_int, [C.c_void_p, C.c_int]),
     "pny_scene_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p]),
     "pny_scene_destroy": (None, [C.c_void_p]),
     "pny_scene_set_cameras": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
@@ -103,6 +104,9 @@ def load():
         raise PnyError(
             "libpnyolo.so not found at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no CPU fallback for the HIP path)" % LIB_PATH)
+    # torch ships its own libamdhip64; it must be loaded FIRST so that libpnyolo.so binds to the
+    # same HIP runtime instance -- streams and device pointers are shared across the boundary.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported

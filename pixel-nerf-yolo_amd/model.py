@@ -216,6 +216,8 @@ class PixelNeRFNet(nn.Module):
         self.num_views_per_obj = 1
         # native handles (created lazily on the module's CUDA device)
         self._h_model = None
+        self._h_device = None
+        self._h_has_fine = False
         self._h_scenes = []
         self._synced_key = None
         self._timing = False
@@ -245,32 +247,41 @@ class PixelNeRFNet(nn.Module):
 
     def _weights_key(self):
         ps = list(self.state_dict(keep_vars=True).items())
-        return (str(self._device()), self.mlp_fine is not None, tuple((k, v.data_ptr(), v._version) for k, v in ps))
+        return tuple((k, v.data_ptr(), v._version) for k, v in ps)
 
     def _sync(self):
-        """(Re)build the native model when parameters changed (load_weights, .to(), optimizer step)."""
-        key = self._weights_key()
-        if self._h_model is not None and key == self._synced_key:
-            return
+        """Create the native model on first use; re-upload weights when parameters changed
+        (load_weights, load_state_dict, optimizer step).  Scenes survive a weight reload; a move to
+        another device rebuilds everything."""
         L = _lib.load()
-        self._free_native()
         dev = self._device()
-        mc = self.mlp_coarse
-        desc = ModelDesc(d_latent=self.d_latent, d_hidden=mc.d_hidden, d_out=self.d_out, n_blocks=mc.n_blocks,
-                         combine_layer=min(mc.combine_layer, 1 << 20), num_freqs=self.code.num_freqs,
-                         freq_factor=float(self.code.freq_factor), yolo=int(self.yolo),
-                         has_fine=int(self.mlp_fine is not None), device=dev.index or 0)
-        h = C.c_void_p()
-        check(L.pny_model_create(C.byref(h), C.byref(desc)))
-        self._h_model = h
-        for name, t in self.state_dict().items():
-            if name.endswith("num_batches_tracked"):
-                continue
-            a = np.ascontiguousarray(t.detach().to("cpu", torch.float32).numpy())
-            shape = (C.c_int64 * max(a.ndim, 1))(*a.shape)
-            check(L.pny_model_load_weights(h, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim))
-        check(L.pny_model_finalize(h))
-        self._synced_key = key
+        if self._h_model is not None and self._h_device != str(dev):
+            self._free_native()
+        key = self._weights_key()
+        if self._h_model is None:
+            mc = self.mlp_coarse
+            has_fine = any(k[0].startswith("mlp_fine.") for k in key)
+            desc = ModelDesc(d_latent=self.d_latent, d_hidden=mc.d_hidden, d_out=self.d_out, n_blocks=mc.n_blocks,
+                             combine_layer=min(mc.combine_layer, 1 << 20), num_freqs=self.code.num_freqs,
+                             freq_factor=float(self.code.freq_factor), yolo=int(self.yolo),
+                             has_fine=int(has_fine), device=dev.index or 0)
+            h = C.c_void_p()
+            check(L.pny_model_create(C.byref(h), C.byref(desc)))
+            self._h_model, self._h_device, self._h_has_fine, self._synced_key = h, str(dev), has_fine, None
+        if self.mlp_fine is not None and not self._h_has_fine:
+            raise RuntimeError("a fine MLP was attached after the native model was created without one")
+        if key != self._synced_key:
+            h = self._h_model
+            for name, t in self.state_dict().items():
+                if name.endswith("num_batches_tracked"):
+                    continue
+                a = np.ascontiguousarray(t.detach().to("cpu", torch.float32).numpy())
+                shape = (C.c_int64 * max(a.ndim, 1))(*a.shape)
+                check(L.pny_model_load_weights(h, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim))
+            check(L.pny_model_finalize(h))
+            self._synced_key = key
+        # `net.mlp_fine = None` (reference eval.py:140): fine pass falls back to the coarse MLP
+        check(L.pny_model_use_fine(self._h_model, int(self.mlp_fine is not None)))
 
     def _scene(self, i):
         L = _lib.load()

@@ -169,20 +169,22 @@ def test_stage_kernels_vs_golden(golden):
     L = plib.load()
     st = plib.stream_of(torch.device(DEV))
     n = 100
-    rays = dt(g["rays"])
+    # device copies are named: a temporary would be freed (and its memory reused) before the launch
+    rays, u_c, z_c, s_c = dt(g["rays"]), dt(g["u_coarse"]), dt(g["z_coarse"]), dt(g["coarse_out"])
+    w_c, d_c = dt(g["coarse_weights"]), dt(g["coarse_depth"])
+    u_f, u_f2, g_d, s_f = dt(g["u_fine"]), dt(g["u_fine2"]), dt(g["g_depth"]), dt(g["fine_out"])
     z = torch.empty(n, 64, device=DEV)
-    plib.check(L.pny_sample_coarse(plib.ptr(rays), n, 64, 0, plib.ptr(dt(g["u_coarse"])), 0, plib.ptr(z), st))
+    plib.check(L.pny_sample_coarse(plib.ptr(rays), n, 64, 0, plib.ptr(u_c), 0, plib.ptr(z), st))
     assert maxabs(z, g["z_coarse"]) == 0.0
     w, rgb, dep = torch.empty(n, 64, device=DEV), torch.empty(n, 3, device=DEV), torch.empty(n, device=DEV)
-    plib.check(L.pny_composite(plib.ptr(rays), plib.ptr(dt(g["z_coarse"])), plib.ptr(dt(g["coarse_out"])), n, 64, 1,
-                               plib.ptr(w), plib.ptr(rgb), plib.ptr(dep), st))
+    plib.check(L.pny_composite(plib.ptr(rays), plib.ptr(z_c), plib.ptr(s_c), n, 64, 1, plib.ptr(w), plib.ptr(rgb),
+                               plib.ptr(dep), st))
     assert maxabs(w, g["coarse_weights"]) < 2e-6
     assert maxabs(rgb, g["coarse_rgb"]) < 2e-6 and maxabs(dep, g["coarse_depth"]) < 2e-6
     # fine sampling + sort on the reference's own coarse weights: same bins, same depths
     zo = torch.empty(n, 96, device=DEV)
-    plib.check(L.pny_sample_fine(plib.ptr(rays), plib.ptr(dt(g["z_coarse"])), plib.ptr(dt(g["coarse_weights"])),
-                                 plib.ptr(dt(g["coarse_depth"])), n, 64, 32, 16, 0.01, 0, plib.ptr(dt(g["u_fine"])),
-                                 plib.ptr(dt(g["u_fine2"])), plib.ptr(dt(g["g_depth"])), 0, plib.ptr(zo), st))
+    plib.check(L.pny_sample_fine(plib.ptr(rays), plib.ptr(z_c), plib.ptr(w_c), plib.ptr(d_c), n, 64, 32, 16, 0.01, 0,
+                                 plib.ptr(u_f), plib.ptr(u_f2), plib.ptr(g_d), 0, plib.ptr(zo), st))
     r = torch.from_numpy(g["rays"])
     zf = orc.sample_fine(r, torch.from_numpy(g["coarse_weights"]), g["u_fine"], g["u_fine2"], 64)
     zd = orc.sample_fine_depth(r, torch.from_numpy(g["coarse_depth"]), g["g_depth"], 0.01)
@@ -191,10 +193,20 @@ def test_stage_kernels_vs_golden(golden):
     assert len(bad) <= 1
     assert bool((zo[:, 1:] >= zo[:, :-1]).all())
     # composite of the fine pass on golden inputs (K = 96 > one wavefront: carried transmittance)
+    z_r = dt(z_ref)
     w2, rgb2 = torch.empty(n, 96, device=DEV), torch.empty(n, 3, device=DEV)
-    plib.check(L.pny_composite(plib.ptr(rays), plib.ptr(dt(z_ref)), plib.ptr(dt(g["fine_out"])), n, 96, 1,
-                               plib.ptr(w2), plib.ptr(rgb2), None, st))
+    plib.check(L.pny_composite(plib.ptr(rays), plib.ptr(z_r), plib.ptr(s_f), n, 96, 1, plib.ptr(w2), plib.ptr(rgb2),
+                               None, st))
+    torch.cuda.synchronize()
     assert maxabs(w2, g["fine_weights"]) < 2e-6 and maxabs(rgb2, g["fine_rgb"]) < 2e-6
+    # in-kernel Philox stream (perf mode): one sample per stratum, deterministic in the seed
+    za, zb = torch.empty(n, 64, device=DEV), torch.empty(n, 64, device=DEV)
+    plib.check(L.pny_sample_coarse(plib.ptr(rays), n, 64, 0, None, 42, plib.ptr(za), st))
+    plib.check(L.pny_sample_coarse(plib.ptr(rays), n, 64, 0, None, 42, plib.ptr(zb), st))
+    assert torch.equal(za, zb)
+    t = (za - 0.8) * 64 - torch.arange(64, device=DEV)
+    assert float(t.min()) >= -1e-4 and float(t.max()) <= 1.0 + 1e-4
+    assert 0.4 < float(t.mean()) < 0.6 and float(t.std()) > 0.2      # jitter is spread over the stratum
 
 
 # --------------------------------------------------------------------------- YOLO mode
