@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--cpu-rays", type=int, default=384, help="ray subset for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-rays", type=int, default=256, help="ray subset for the CPU baseline (0 = skip)")
     ap.add_argument("--describe", action="store_true", help="print the workload description and exit (no GPU)")
     args = ap.parse_args()
     if args.describe:
@@ -189,7 +189,8 @@ def main():
         sub = rays[0, torch.from_numpy(rs.choice(n_rays, nb, replace=False)).to(dev)].cpu()
         draws = (rs.rand(nb, KC).astype(np.float32), rs.rand(nb, KF - KFD).astype(np.float32),
                  rs.rand(nb, KF - KFD).astype(np.float32), rs.randn(nb, KFD).astype(np.float32))
-        torch.set_num_threads(os.cpu_count() or 1)
+        # the box's CPU share for one GPU is 16 cores (more threads only oversubscribe the small GEMMs)
+        torch.set_num_threads(min(os.cpu_count() or 1, 16))
         t0 = time.perf_counter()
         orc.render(sc, sub, KC, KF, KFD, *draws, chunk=50000)
         cpu_s = time.perf_counter() - t0

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Condenses a gpurun_out/prof_<tag>/ directory (tools/profile_gpu.sh) into profiles/<tag>_summary.md:
+per-kernel time table from the kernel trace and per-dispatch PMC averages for the MLP kernel."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def rows(pattern):
+    for f in glob.glob(pattern, recursive=True):
+        with open(f, newline="") as fh:
+            for r in csv.DictReader(fh):
+                yield r
+
+
+def main(tag):
+    src = os.path.join("gpurun_out", "prof_" + tag)
+    out = [f"# rocprofv3 summary `{tag}` (bench.py --steps 2 --warmup 1 --cpu-rays 0, 1x MI355X)\n"]
+    # ---- kernel trace
+    agg = defaultdict(lambda: [0, 0.0, 1e30, 0.0])
+    for r in rows(os.path.join(src, "trace", "**", "*kernel_trace.csv")):
+        name = r["Kernel_Name"].split("(")[0]
+        dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+        a = agg[name]
+        a[0] += 1
+        a[1] += dur
+        a[2] = min(a[2], dur)
+        a[3] = max(a[3], dur)
+    tot = sum(a[1] for a in agg.values()) or 1.0
+    out.append("## Kernel trace (`--kernel-trace --stats`)\n")
+    out.append("| kernel | calls | total ms | avg ms | min ms | max ms | % |")
+    out.append("|---|---|---|---|---|---|---|")
+    for name, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        out.append(f"| `{name[:70]}` | {a[0]} | {a[1]:.3f} | {a[1]/a[0]:.3f} | {a[2]:.3f} | {a[3]:.3f} | {100*a[1]/tot:.2f} |")
+    # ---- PMC passes
+    out.append("\n## PMC counters, pny_mlp_kernel dispatches only (separate `--pmc` passes; per-dispatch mean)\n")
+    out.append("| pass | counter | mean per dispatch | dispatches |")
+    out.append("|---|---|---|---|")
+    for p in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+        if not os.path.isdir(p):
+            continue
+        acc = defaultdict(lambda: [0, 0.0])
+        for r in rows(os.path.join(p, "**", "*counter_collection.csv")):
+            if "pny_mlp_kernel" not in r.get("Kernel_Name", ""):
+                continue
+            a = acc[r["Counter_Name"]]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+        for cname, a in sorted(acc.items()):
+            out.append(f"| {os.path.basename(p)} | {cname} | {a[1]/max(a[0],1):.6g} | {a[0]} |")
+    os.makedirs("profiles", exist_ok=True)
+    dst = os.path.join("profiles", tag + "_summary.md")
+    with open(dst, "w") as fh:
+        fh.write("\n".join(out) + "\n")
+    print("\n".join(out))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "r01")
