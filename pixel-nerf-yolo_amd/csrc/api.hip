@@ -142,19 +142,34 @@ static int pack_mlp(pny_model* m, const std::string& pre, MlpWeights& w, PackPla
         plan.fix.push_back({slot, plan.add_plain(t->data)});
         return 0;
     };
+    // `x = x + lin_z[b](z)` (resnetfc.py:176-182) happens right after lin_in (b = 0) or right after
+    // the previous block's fc_1 (b > 0): its bias is folded into that layer's bias here, so the kernel
+    // has one bias vector per GEMM chain link and no separate bias pass.
+    auto plain_plus = [&](const std::string& name, const std::string& extra, const float** slot) -> int {
+        const HostTensor* t2 = nullptr;
+        if ((rc = need(m, name, {HID}, &t))) return rc;
+        std::vector<float> sum = t->data;
+        if (!extra.empty()) {
+            if ((rc = need(m, extra, {HID}, &t2))) return rc;
+            for (int i = 0; i < HID; ++i) sum[i] += t2->data[i];
+        }
+        plan.fix.push_back({slot, plan.add_plain(sum)});
+        return 0;
+    };
+    auto zbias = [&](int b) { return b < nvb ? pre + "lin_z." + std::to_string(b) + ".bias" : std::string(); };
     if ((rc = packed(pre + "lin_in.weight", d_in, D_IN_PAD, &w.w_in))) return rc;
-    if ((rc = plain(pre + "lin_in.bias", {HID}, &w.b_in))) return rc;
+    if ((rc = plain_plus(pre + "lin_in.bias", zbias(0), &w.b_in))) return rc;
     for (int b = 0; b < nvb; ++b) {
         const std::string p = pre + "lin_z." + std::to_string(b);
         if ((rc = packed(p + ".weight", d.d_latent, d.d_latent, &w.w_z[b]))) return rc;
-        if ((rc = plain(p + ".bias", {HID}, &w.b_z[b]))) return rc;
+        w.b_z[b] = nullptr;  // folded
     }
     for (int b = 0; b < d.n_blocks; ++b) {
         const std::string p = pre + "blocks." + std::to_string(b);
         if ((rc = packed(p + ".fc_0.weight", HID, HID, &w.w_fc0[b]))) return rc;
         if ((rc = plain(p + ".fc_0.bias", {HID}, &w.b_fc0[b]))) return rc;
         if ((rc = packed(p + ".fc_1.weight", HID, HID, &w.w_fc1[b]))) return rc;
-        if ((rc = plain(p + ".fc_1.bias", {HID}, &w.b_fc1[b]))) return rc;
+        if ((rc = plain_plus(p + ".fc_1.bias", zbias(b + 1), &w.b_fc1[b]))) return rc;
     }
     if ((rc = plain(pre + "lin_out.weight", {d.d_out, HID}, &w.w_out))) return rc;
     if ((rc = plain(pre + "lin_out.bias", {d.d_out}, &w.b_out))) return rc;
@@ -492,13 +507,14 @@ static int run_mlp(pny_scene* s, int mode, const float* xyz, const float* dirs, 
     const float lsy = (float)s->hl / ((float)s->hl - 1.0f) * 2.0f;
     a.sx = lsx / (float)s->width;
     a.sy = lsy / (float)s->height;
-    const long long tiles = (n_points + TM - 1) / TM;
+    const int tm = mlp_tile_samples();
+    const long long tiles = (n_points + tm - 1) / tm;
     if (tiles > 0x7fffffffll) return fail(PNY_ERR_ARG, "too many points for one launch");
     a.n_tiles = (int)tiles;
     int grid = mlp_max_grid();
     if (tiles < grid) grid = (int)tiles;
     int rc;
-    if ((rc = s->scratch.reserve((size_t)mlp_max_grid() * TM * HID * sizeof(float)))) return rc;
+    if ((rc = s->scratch.reserve(mlp_scratch_floats() * sizeof(float)))) return rc;
     a.scratch = s->scratch.f();
     if (s->timing) {
         while ((int)s->ev.size() < s->ev_used + 2) {

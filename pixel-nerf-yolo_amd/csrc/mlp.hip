@@ -21,11 +21,40 @@
 //     (channel-last latent, 16-byte loads, 128-byte lines per 8 lanes).
 //   * one workgroup per CU (LDS bound), persistent over tiles; cross-view running sum lives in
 //     a per-workgroup L2-resident scratch slab (128 KiB).
+#include <cstdlib>
+
 #include "pny_common.h"
+#ifdef PNY_STAMP
+#include <cstdio>
+#include <vector>
+#endif
 
 namespace pny {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Diagnostic build only (-DPNY_STAMP, tools/stamp_build.sh): s_memtime brackets around the phases
+// of a tile, summed per wave and dumped by launch_mlp.  No stamp executes in the product build.
+#ifdef PNY_STAMP
+enum { ST_TOTAL = 0, ST_GEMM, ST_GATHER, ST_PROLOGUE, ST_STORE, ST_HSUM, ST_LINOUT, ST_SYNC1, ST_WRITE, ST_SYNC2, ST_N };
+__device__ unsigned long long* g_stamp_buf;
+__device__ __forceinline__ unsigned long long stamp_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define ST_BEGIN() const unsigned long long st_t0_ = stamp_now()
+#define ST_END(cat) st_acc[cat] += stamp_now() - st_t0_
+#define ST_ARG , unsigned long long (&st_acc)[ST_N]
+#define ST_PASS , st_acc
+#else
+#define ST_BEGIN()
+#define ST_END(cat)
+#define ST_ARG
+#define ST_PASS
+#endif
 
 // ---- accumulator <-> feature mapping of v_mfma_f32_32x32x2_f32 -------------------------------
 // lane l = 32*hh + m0.  acc[nt][mt] register r holds
@@ -35,70 +64,150 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // successive MFMAs.  A operand: packed so that lane reads float4 #lane of block (nt, j) holding
 //     W[32*nt_global + m0][8j + 4hh + 0..3].
 
-__device__ __forceinline__ void gemm_tile(f32x16 (&acc)[2][2], const float4* __restrict__ wp, int jtot, int jn,
-                                          const float4* __restrict__ act, int lane) {
-    const int m0 = lane & 31, hh = lane >> 5;
-    const float4* w0 = wp + lane;                       // n-tile 0 of this wave
-    const float4* w1 = wp + (size_t)jtot * 64 + lane;   // n-tile 1
-    const float4* bp = act + hh * TM + m0;
-    float4 a0 = w0[0], a1 = w1[0];
-    for (int j = 0; j < jn; ++j) {
-        const int jn1 = (j + 1 < jn) ? j + 1 : j;
-        const float4 na0 = w0[(size_t)jn1 * 64];
-        const float4 na1 = w1[(size_t)jn1 * 64];
-        const float4 b0 = bp[(2 * j) * TM];
-        const float4 b1 = bp[(2 * j) * TM + 32];
-#define PNY_STEP(c)                                                                          \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c, b0.c, acc[0][0], 0, 0, 0);        \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c, b1.c, acc[0][1], 0, 0, 0);        \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c, b0.c, acc[1][0], 0, 0, 0);        \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c, b1.c, acc[1][1], 0, 0, 0);
-        PNY_STEP(x)
-        PNY_STEP(y)
-        PNY_STEP(z)
-        PNY_STEP(w)
+// One k-iteration (8 input features = 4 MFMA k-steps) of the wave's 2 x MT tile.
+template <int MT>
+__device__ __forceinline__ void mfma_iter(f32x16 (&acc)[2][MT], const float4& a0, const float4& a1,
+                                          const float4 (&b)[MT]) {
+#define PNY_STEP(c)                                                                                  \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                \
+        acc[0][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c, b[mt].c, acc[0][mt], 0, 0, 0);       \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                \
+        acc[1][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c, b[mt].c, acc[1][mt], 0, 0, 0);
+    PNY_STEP(x)
+    PNY_STEP(y)
+    PNY_STEP(z)
+    PNY_STEP(w)
 #undef PNY_STEP
-        a0 = na0;
-        a1 = na1;
+}
+
+// The weights of all layers form ONE stream per wave: 13.7 MB per MLP cannot stay in the XCD's
+// 4 MiB L2, and the 32 CUs of an XCD reach a layer together, so the first touch of every line is an
+// Infinity-Cache access (~3 us under load) for everybody.  A register ring therefore keeps the next
+// WDepth<MT> k-iterations of fragments in flight and runs ACROSS layer boundaries: while a GEMM
+// drains, the ring already fills with the head of the next layer's slice (WSeg next), so neither
+// the epilogue/barrier phase nor the head of a GEMM waits on memory.
+constexpr int WDEPTH_MAX = 4;
+template <int MT>
+struct WDepth {
+    static constexpr int value = MT == 1 ? 2 : 4;  // 128-VGPR (tile 32) variant cannot afford 4
+};
+
+struct WSeg {  // this wave's slice of one packed layer: fragment j of n-tile t at w[t][j * 64]
+    const float4* w[2];
+    int jn;
+};
+__device__ __forceinline__ WSeg wseg(const float* packed, int jtot, int j0, int jn, int wave, int lane) {
+    WSeg s;
+    s.w[0] = reinterpret_cast<const float4*>(packed) + ((size_t)(2 * wave) * jtot + j0) * 64 + lane;
+    s.w[1] = s.w[0] + (size_t)jtot * 64;
+    s.jn = jn;
+    return s;
+}
+
+template <int D>
+struct WRing {
+    float4 f[D][2];
+};
+
+template <int D>
+__device__ __forceinline__ void ring_fill(WRing<D>& r, const WSeg& s) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const int j = d < s.jn ? d : s.jn - 1;
+        r.f[d][0] = s.w[0][(size_t)j * 64];
+        r.f[d][1] = s.w[1][(size_t)j * 64];
     }
 }
 
-// acc += bias[n] (broadcast over samples)
-__device__ __forceinline__ void add_bias(f32x16 (&acc)[2][2], const float* __restrict__ bias, int wave, int lane) {
-    const int hh = lane >> 5;
+// acc += W_slice * act over segment `cur`; leaves the ring holding the first WDEPTH fragments of
+// `next`.  Activation fragments (LDS) run one iteration ahead.  sched_barrier pins the issue order
+// so the compiler cannot sink the loads back next to their uses (it did in the first build).
+template <int MT>
+__device__ __forceinline__ void gemm_run(f32x16 (&acc)[2][MT], WRing<WDepth<MT>::value>& r, const WSeg& cur, const WSeg& next,
+                                         const float4* __restrict__ act, int lane) {
+    constexpr int TMc = 32 * MT, WDEPTH = WDepth<MT>::value;
+    const int m0 = lane & 31, hh = lane >> 5;
+    const float4* bp = act + hh * TMc + m0;
+    const int jn = cur.jn, jl = jn - 1;
+    float4 bc[MT], bn[MT];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
+    for (int mt = 0; mt < MT; ++mt) bc[mt] = bp[32 * mt];
+    for (int j = 0; j < jn; ++j) {
+        int jj = j + WDEPTH;
+#ifdef PNY_EXP_NOWSTREAM  // timing-only experiment: no weight streaming (wrong results)
+        jj = 0;
+#endif
+        const bool in_cur = jj < jn;
+        int jx = in_cur ? jj : jj - jn;
+        if (!in_cur && jx >= next.jn) jx = next.jn - 1;
+        const float4* s0 = in_cur ? cur.w[0] : next.w[0];
+        const float4* s1 = in_cur ? cur.w[1] : next.w[1];
+        const float4 q0 = s0[(size_t)jx * 64];
+        const float4 q1 = s1[(size_t)jx * 64];
+        const int j1 = (j + 1 < jl) ? j + 1 : jl;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 b = *reinterpret_cast<const float4*>(bias + 64 * wave + 32 * nt + 8 * q + 4 * hh);
+        for (int mt = 0; mt < MT; ++mt) bn[mt] = bp[(2 * j1) * TMc + 32 * mt];
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_iter<MT>(acc, r.f[0][0], r.f[0][1], bc);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                acc[nt][mt][4 * q + 0] += b.x;
-                acc[nt][mt][4 * q + 1] += b.y;
-                acc[nt][mt][4 * q + 2] += b.z;
-                acc[nt][mt][4 * q + 3] += b.w;
-            }
+        for (int d = 0; d + 1 < WDEPTH; ++d) {
+            r.f[d][0] = r.f[d + 1][0];
+            r.f[d][1] = r.f[d + 1][1];
         }
+        r.f[WDEPTH - 1][0] = q0;
+        r.f[WDEPTH - 1][1] = q1;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) bc[mt] = bn[mt];
     }
 }
 
-__device__ __forceinline__ void set_bias(f32x16 (&acc)[2][2], const float* __restrict__ bias, int wave, int lane) {
+// A lane's slice of a 512-entry bias: features 64*wave + 32*nt + 8*q + 4*hh + 0..3.  Loaded before
+// a barrier phase (bias_load) and applied after it, so its latency is not exposed either.
+struct BiasRegs {
+    float4 v[2][4];
+};
+
+__device__ __forceinline__ void bias_load(BiasRegs& b, const float* __restrict__ bias, int wave, int lane) {
+    const int hh = lane >> 5;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int q = 0; q < 4; ++q)
+            b.v[nt][q] = *reinterpret_cast<const float4*>(bias + 64 * wave + 32 * nt + 8 * q + 4 * hh);
+}
+
+template <int MT, bool ADD>
+__device__ __forceinline__ void bias_apply(f32x16 (&acc)[2][MT], const BiasRegs& b) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.f;
-    add_bias(acc, bias, wave, lane);
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if (ADD) {
+                    acc[nt][mt][4 * q + 0] += b.v[nt][q].x;
+                    acc[nt][mt][4 * q + 1] += b.v[nt][q].y;
+                    acc[nt][mt][4 * q + 2] += b.v[nt][q].z;
+                    acc[nt][mt][4 * q + 3] += b.v[nt][q].w;
+                } else {
+                    acc[nt][mt][4 * q + 0] = b.v[nt][q].x;
+                    acc[nt][mt][4 * q + 1] = b.v[nt][q].y;
+                    acc[nt][mt][4 * q + 2] = b.v[nt][q].z;
+                    acc[nt][mt][4 * q + 3] = b.v[nt][q].w;
+                }
+            }
 }
 
 // act[feature/4][m] = relu(acc): the next layer's B operand.
-__device__ __forceinline__ void store_relu(const f32x16 (&acc)[2][2], float4* __restrict__ act, int wave, int lane) {
+template <int MT>
+__device__ __forceinline__ void store_relu(const f32x16 (&acc)[2][MT], float4* __restrict__ act, int wave, int lane) {
+    constexpr int TMc = 32 * MT;
     const int m0 = lane & 31, hh = lane >> 5;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float4 v;
@@ -107,25 +216,98 @@ __device__ __forceinline__ void store_relu(const f32x16 (&acc)[2][2], float4* __
                 v.z = fmaxf(acc[nt][mt][4 * q + 2], 0.f);
                 v.w = fmaxf(acc[nt][mt][4 * q + 3], 0.f);
                 const int kg = 16 * wave + 8 * nt + 2 * q + hh;
-                act[kg * TM + 32 * mt + m0] = v;
+                act[kg * TMc + 32 * mt + m0] = v;
             }
+}
+
+// Cross-view running sum slab (per workgroup, coalesced: register r of lane l at [r][l]).  It is
+// written and read with non-temporal accesses: 32 CUs x 128 KiB would otherwise evict the layer
+// weights from the XCD's 4 MiB L2 three times per tile.
+template <int MT>
+__device__ __forceinline__ void slab_store(const f32x16 (&h)[2][MT], float* slab) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(h[nt][mt][r], slab + ((nt * MT + mt) * 16 + r) * 64);
+}
+template <int MT>
+__device__ __forceinline__ void slab_load(f32x16 (&t)[2][MT], const float* slab) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[nt][mt][r] = __builtin_nontemporal_load(slab + ((nt * MT + mt) * 16 + r) * 64);
 }
 
 // One pre-activation residual block (reference resnetfc.py:53-62):
 //   net = fc_0(relu(h)); h = h + fc_1(relu(net))
-__device__ __forceinline__ void res_block(f32x16 (&h)[2][2], const MlpWeights& w, int blk, float4* act, int wave,
-                                          int lane) {
-    f32x16 net[2][2];
-    __syncthreads();
-    store_relu(h, act, wave, lane);
-    __syncthreads();
-    set_bias(net, w.b_fc0[blk], wave, lane);
-    gemm_tile(net, reinterpret_cast<const float4*>(w.w_fc0[blk]) + (size_t)(2 * wave) * 64 * 64, 64, 64, act, lane);
-    __syncthreads();
-    store_relu(net, act, wave, lane);
-    __syncthreads();
-    add_bias(h, w.b_fc1[blk], wave, lane);
-    gemm_tile(h, reinterpret_cast<const float4*>(w.w_fc1[blk]) + (size_t)(2 * wave) * 64 * 64, 64, 64, act, lane);
+// b_fc1 already contains the next block's lin_z bias (folded on the host, api.hip).
+// `after` is the weight segment that follows this block in the stream.  With slab != nullptr the
+// other views' running sum is fetched into the (then dead) net registers underneath the fc_1
+// GEMM and added to h afterwards.
+template <int MT>
+__device__ __forceinline__ void res_block(f32x16 (&h)[2][MT], WRing<WDepth<MT>::value>& ring, const MlpWeights& w, int blk,
+                                          const WSeg& after, float4* act, int wave, int lane,
+                                          const float* slab ST_ARG) {
+    f32x16 net[2][MT];
+    BiasRegs bias;
+    const WSeg s_fc0 = wseg(w.w_fc0[blk], 64, 0, 64, wave, lane);
+    const WSeg s_fc1 = wseg(w.w_fc1[blk], 64, 0, 64, wave, lane);
+    {
+        ST_BEGIN();
+        bias_load(bias, w.b_fc0[blk], wave, lane);
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef PNY_STAMP
+        const unsigned long long f0 = stamp_now();
+        __syncthreads();
+        const unsigned long long f1 = stamp_now();
+        store_relu(h, act, wave, lane);
+        const unsigned long long f2 = stamp_now();
+        __syncthreads();
+        const unsigned long long f3 = stamp_now();
+        st_acc[ST_SYNC1] += f1 - f0;
+        st_acc[ST_WRITE] += f2 - f1;
+        st_acc[ST_SYNC2] += f3 - f2;
+#else
+        __syncthreads();
+        store_relu(h, act, wave, lane);
+        __syncthreads();
+#endif
+        bias_apply<MT, false>(net, bias);
+        ST_END(ST_STORE);
+    }
+    {
+        ST_BEGIN();
+        gemm_run(net, ring, s_fc0, s_fc1, act, lane);
+        ST_END(ST_GEMM);
+    }
+    {
+        ST_BEGIN();
+        bias_load(bias, w.b_fc1[blk], wave, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        store_relu(net, act, wave, lane);
+        if (slab) slab_load(net, slab);
+        __syncthreads();
+        bias_apply<MT, true>(h, bias);
+        ST_END(ST_STORE);
+    }
+    {
+        ST_BEGIN();
+        gemm_run(h, ring, s_fc1, after, act, lane);
+        ST_END(ST_GEMM);
+    }
+    if (slab) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) h[nt][mt][r] = net[nt][mt][r] + h[nt][mt][r];
+    }
 }
 
 __device__ __forceinline__ void load_point(const MlpArgs& a, long long s, float (&p)[3], float (&d)[3]) {
@@ -167,10 +349,12 @@ __device__ __forceinline__ float input_entry(int e, const float (&xr)[3], const 
 
 // Per (view, tile) prologue: B operand of lin_in into act k-groups 0..11, and the four bilinear
 // taps of every sample into the tap table.
+template <int MT>
 __device__ __forceinline__ void prologue(const MlpArgs& a, int v, long long tile, float4* act, int* tap_off,
                                          float* tap_w, int tid) {
-    const int m = tid & 63, part = tid >> 6;
-    long long s = tile * TM + m;
+    constexpr int TMc = 32 * MT, NPART = MLP_THREADS / TMc;
+    const int m = tid % TMc, part = tid / TMc;
+    long long s = tile * TMc + m;
     if (s >= a.n_points) s = a.n_points - 1;
     float p[3], d[3];
     load_point(a, s, p, d);
@@ -182,15 +366,15 @@ __device__ __forceinline__ void prologue(const MlpArgs& a, int v, long long tile
         xc[i] = xr[i] + cam.w2c[4 * i + 3];
         vd[i] = cam.w2c[4 * i + 0] * d[0] + cam.w2c[4 * i + 1] * d[1] + cam.w2c[4 * i + 2] * d[2];
     }
-    for (int g = part; g < D_IN_PAD / 4; g += 8) {
+    for (int g = part; g < D_IN_PAD / 4; g += NPART) {
         float4 x4;
         x4.x = input_entry(4 * g + 0, xr, vd, a.freq_factor, a.num_freqs);
         x4.y = input_entry(4 * g + 1, xr, vd, a.freq_factor, a.num_freqs);
         x4.z = input_entry(4 * g + 2, xr, vd, a.freq_factor, a.num_freqs);
         x4.w = input_entry(4 * g + 3, xr, vd, a.freq_factor, a.num_freqs);
-        act[g * TM + m] = x4;
+        act[g * TMc + m] = x4;
     }
-    if (part == 7) {
+    if (part == NPART - 1) {
         // projection (reference models.py:219-230) and grid_sample coordinates
         // (encoder.py:97-98, align_corners=True, zeros padding)
         float ux, uy;
@@ -223,104 +407,166 @@ __device__ __forceinline__ void prologue(const MlpArgs& a, int v, long long tile
                 wk = wk * 0.0f;  // out-of-range tap contributes 0 (NaN coordinates stay NaN, as in ATen)
             }
             if (cull || (a.yolo && (wk != wk))) wk = 0.0f;
-            tap_off[k * TM + m] = off;
-            tap_w[k * TM + m] = wk;
+            tap_off[k * TMc + m] = off;
+            tap_w[k * TMc + m] = wk;
         }
     }
 }
 
-// Bilinear gather of latent channels [c0, c0 + 4*nq) of view v for all 64 samples into the
-// B-operand layout act[(c - c0)/4][m].  A wave pass covers 8 samples x 8 channel quads: each
-// group of lanes {l, l+8, .., l+56} reads one 128-byte line per tap, each 8-lane group writes
-// 128 contiguous LDS bytes.
+// Bilinear gather of latent channels [c0, c0 + 4*nq) of view v for all samples of the tile into
+// the B-operand layout act[(c - c0)/4][m].  A wave pass covers 8 samples x 8 channel quads: the
+// lanes {l, l+8, .., l+56} read one 128-byte line per tap, each 8-lane group writes 128
+// contiguous LDS bytes.  A lane keeps the same sample for the whole gather, so its four tap
+// offsets / weights are read once and the loop body is 4 independent 16-byte loads per pass.
+template <int MT>
 __device__ __forceinline__ void gather_latent(const MlpArgs& a, int v, int c0, int nq, float4* act,
                                               const int* tap_off, const float* tap_w, int wave, int lane) {
-    const float* base = a.latent + (size_t)v * a.Hl * a.Wl * a.L + c0;
-    const int ml = lane & 7, ql = lane >> 3;
+    constexpr int TMc = 32 * MT, NMB = TMc / 8;  // sample blocks of 8
+    constexpr int QSTEP = 8 / NMB;               // q-blocks advanced per pass of the 8 waves
+    const int m = (wave % NMB) * 8 + (lane & 7);
+    const int ql = lane >> 3;
+    const float* base = a.latent + (size_t)v * a.Hl * a.Wl * a.L + c0 + 4 * ql;
+    const float* t0 = base + tap_off[0 * TMc + m];
+    const float* t1 = base + tap_off[1 * TMc + m];
+    const float* t2 = base + tap_off[2 * TMc + m];
+    const float* t3 = base + tap_off[3 * TMc + m];
+    const float w0 = tap_w[0 * TMc + m], w1 = tap_w[1 * TMc + m], w2 = tap_w[2 * TMc + m], w3 = tap_w[3 * TMc + m];
+    float4* dst = act + ql * TMc + m;
     const int nqb = nq >> 3;
-    for (int it = wave; it < 8 * nqb; it += 8) {
-        const int m = (it & 7) * 8 + ml;
-        const int q = (it >> 3) * 8 + ql;
-        float4 acc4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float wk = tap_w[k * TM + m];
-            const float4 t = *reinterpret_cast<const float4*>(base + tap_off[k * TM + m] + 4 * q);
-            acc4.x += t.x * wk;
-            acc4.y += t.y * wk;
-            acc4.z += t.z * wk;
-            acc4.w += t.w * wk;
-        }
-        act[q * TM + m] = acc4;
+#pragma unroll 4
+    for (int qb = wave / NMB; qb < nqb; qb += QSTEP) {
+        const float4 x0 = *reinterpret_cast<const float4*>(t0 + 32 * qb);
+        const float4 x1 = *reinterpret_cast<const float4*>(t1 + 32 * qb);
+        const float4 x2 = *reinterpret_cast<const float4*>(t2 + 32 * qb);
+        const float4 x3 = *reinterpret_cast<const float4*>(t3 + 32 * qb);
+        float4 r;  // ATen order: nw*w + ne*w + sw*w + se*w
+        r.x = ((x0.x * w0 + x1.x * w1) + x2.x * w2) + x3.x * w3;
+        r.y = ((x0.y * w0 + x1.y * w1) + x2.y * w2) + x3.y * w3;
+        r.z = ((x0.z * w0 + x1.z * w1) + x2.z * w2) + x3.z * w3;
+        r.w = ((x0.w * w0 + x1.w * w1) + x2.w * w2) + x3.w * w3;
+        dst[(size_t)(8 * qb) * TMc] = r;
     }
 }
 
-__global__ __launch_bounds__(MLP_THREADS, 2) void pny_mlp_kernel(const MlpArgs a) {
+template <int MT>
+__global__ __launch_bounds__(MLP_THREADS, MT == 1 ? 4 : 2) void pny_mlp_kernel(const MlpArgs a) {
+    constexpr int TMc = 32 * MT;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float4* act = reinterpret_cast<float4*>(smem_raw);
-    int* tap_off = reinterpret_cast<int*>(smem_raw + ACT_KG * TM * 16);
-    float* tap_w = reinterpret_cast<float*>(smem_raw + ACT_KG * TM * 16 + 1024);
+    int* tap_off = reinterpret_cast<int*>(smem_raw + ACT_KG * TMc * 16);
+    float* tap_w = reinterpret_cast<float*>(smem_raw + ACT_KG * TMc * 16 + 16 * TMc);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float* slab = a.scratch + (size_t)blockIdx.x * (TM * HID) + (size_t)wave * (4 * 16 * 64) + lane;
+    float* slab = a.scratch + (size_t)blockIdx.x * (TMc * HID) + (size_t)wave * (2 * MT * 16 * 64) + lane;
     const int jz_tot = a.L / 8;
+#ifdef PNY_STAMP
+    unsigned long long st_acc[ST_N];
+    for (int i = 0; i < ST_N; ++i) st_acc[i] = 0;
+    const unsigned long long st_start = stamp_now();
+#endif
+
+    const int n_view_blocks = a.combine_layer < a.n_blocks ? a.combine_layer : a.n_blocks;
+    // weight segments of the stream (this wave's slices), in execution order:
+    //   per view: lin_in, then per view-block: lin_z chunks, fc_0, fc_1; then the post-combine blocks
+    const WSeg s_in = wseg(a.w.w_in, D_IN_PAD / 8, 0, D_IN_PAD / 8, wave, lane);
+    auto zseg = [&](int blk, int c0) {
+        const int nch = (a.L - c0) < 4 * ACT_KG ? (a.L - c0) : 4 * ACT_KG;
+        return wseg(a.w.w_z[blk], jz_tot, c0 / 8, nch / 8, wave, lane);
+    };
+    // segment that follows the per-view part of view v (after its last view-block)
+    auto after_view = [&](int v) {
+        if (v + 1 < a.NS) return s_in;
+        if (n_view_blocks < a.n_blocks) return wseg(a.w.w_fc0[n_view_blocks], 64, 0, 64, wave, lane);
+        return s_in;  // next tile
+    };
+    WRing<WDepth<MT>::value> ring;
+    ring_fill(ring, s_in);
 
     for (long long tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-        f32x16 h[2][2];
-        const int n_view_blocks = a.combine_layer < a.n_blocks ? a.combine_layer : a.n_blocks;
+        f32x16 h[2][MT];
         for (int v = 0; v < a.NS; ++v) {
-            __syncthreads();
-            prologue(a, v, tile, act, tap_off, tap_w, tid);
-            __syncthreads();
-            set_bias(h, a.w.b_in, wave, lane);
-            gemm_tile(h, reinterpret_cast<const float4*>(a.w.w_in) + (size_t)(2 * wave) * (D_IN_PAD / 8) * 64,
-                      D_IN_PAD / 8, D_IN_PAD / 8, act, lane);
+            BiasRegs bias;
+            {
+                ST_BEGIN();
+                bias_load(bias, a.w.b_in, wave, lane);  // b_in + b_z[0] (folded on the host)
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();
+                prologue<MT>(a, v, tile, act, tap_off, tap_w, tid);
+                __syncthreads();
+                bias_apply<MT, false>(h, bias);
+                ST_END(ST_PROLOGUE);
+            }
+            {
+                ST_BEGIN();
+                gemm_run(h, ring, s_in, n_view_blocks > 0 ? zseg(0, 0) : after_view(v), act, lane);
+                ST_END(ST_GEMM);
+            }
             for (int blk = 0; blk < n_view_blocks; ++blk) {
-                // x = x + lin_z[blk](z)  (reference resnetfc.py:176-182)
+                // x = x + lin_z[blk](z)  (reference resnetfc.py:176-182); bias folded upstream
                 for (int c0 = 0; c0 < a.L; c0 += 4 * ACT_KG) {
                     const int nch = (a.L - c0) < 4 * ACT_KG ? (a.L - c0) : 4 * ACT_KG;
-                    __syncthreads();
-                    gather_latent(a, v, c0, nch / 4, act, tap_off, tap_w, wave, lane);
-                    __syncthreads();
-                    gemm_tile(h,
-                              reinterpret_cast<const float4*>(a.w.w_z[blk]) + ((size_t)(2 * wave) * jz_tot + c0 / 8) * 64,
-                              jz_tot, nch / 8, act, lane);
+                    {
+                        ST_BEGIN();
+                        __syncthreads();
+                        gather_latent<MT>(a, v, c0, nch / 4, act, tap_off, tap_w, wave, lane);
+                        __syncthreads();
+                        ST_END(ST_GATHER);
+                    }
+                    ST_BEGIN();
+                    const bool more = c0 + 4 * ACT_KG < a.L;
+                    gemm_run(h, ring, zseg(blk, c0),
+                             more ? zseg(blk, c0 + 4 * ACT_KG) : wseg(a.w.w_fc0[blk], 64, 0, 64, wave, lane), act, lane);
+                    ST_END(ST_GEMM);
                 }
-                add_bias(h, a.w.b_z[blk], wave, lane);
-                res_block(h, a.w, blk, act, wave, lane);
+                // the last per-view block also folds in the running sum over the views done so far
+                // (reference util.py:489-499 combine_interleaved, mean over the NS views)
+                const bool last = (blk == n_view_blocks - 1);
+                res_block<MT>(h, ring, a.w, blk, last ? after_view(v) : zseg(blk + 1, 0), act, wave, lane,
+                              (last && v > 0) ? slab : nullptr ST_PASS);
             }
             if (a.NS > 1) {
-                // running sum over views (reference util.py:489-499 combine_interleaved, mean)
+                ST_BEGIN();
+                if (n_view_blocks == 0 && v > 0) {  // degenerate combine_layer = 0: no block to hide the fetch under
+                    f32x16 t[2][MT];
+                    slab_load(t, slab);
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+                    for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
+                        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            float* p = slab + ((nt * 2 + mt) * 16 + r) * 64;
-                            if (v == 0) {
-                                *p = h[nt][mt][r];
-                            } else if (v + 1 < a.NS) {
-                                *p = *p + h[nt][mt][r];
-                            } else {
-                                h[nt][mt][r] = (*p + h[nt][mt][r]) / (float)a.NS;
-                            }
-                        }
+                            for (int r = 0; r < 16; ++r) h[nt][mt][r] = t[nt][mt][r] + h[nt][mt][r];
+                }
+                if (v + 1 < a.NS) {
+                    slab_store(h, slab);
+                } else {
+                    const float ns = (float)a.NS;
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) h[nt][mt][r] = h[nt][mt][r] / ns;
+                }
+                ST_END(ST_HSUM);
             }
         }
-        for (int blk = n_view_blocks; blk < a.n_blocks; ++blk) res_block(h, a.w, blk, act, wave, lane);
+        for (int blk = n_view_blocks; blk < a.n_blocks; ++blk)
+            res_block<MT>(h, ring, a.w, blk,
+                          blk + 1 < a.n_blocks ? wseg(a.w.w_fc0[blk + 1], 64, 0, 64, wave, lane) : s_in, act, wave, lane,
+                          nullptr ST_PASS);
 
         // out = lin_out(relu(h)) (reference resnetfc.py:185) + output head (models.py:312-317)
+        ST_BEGIN();
         __syncthreads();
         store_relu(h, act, wave, lane);
         __syncthreads();
-        for (int idx = tid; idx < a.d_out * TM; idx += MLP_THREADS) {
-            const int o = idx >> 6, m = idx & 63;
+        for (int idx = tid; idx < a.d_out * TMc; idx += MLP_THREADS) {
+            const int o = idx / TMc, m = idx % TMc;
             const float4* wrow = reinterpret_cast<const float4*>(a.w.w_out + (size_t)o * HID);
             float sum = 0.f;
 #pragma unroll 8
             for (int kg = 0; kg < ACT_KG; ++kg) {
-                const float4 x = act[kg * TM + m];
+                const float4 x = act[kg * TMc + m];
                 const float4 ww = wrow[kg];
                 sum += x.x * ww.x;
                 sum += x.y * ww.y;
@@ -334,27 +580,79 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void pny_mlp_kernel(const MlpArgs a
                 else if (o == 3)
                     sum = fmaxf(sum, 0.f);
             }
-            const long long s = tile * TM + m;
+            const long long s = tile * TMc + m;
             if (s < a.n_points) a.out[s * a.d_out + o] = sum;
         }
+        ST_END(ST_LINOUT);
     }
+#ifdef PNY_STAMP
+    st_acc[ST_TOTAL] = stamp_now() - st_start;
+    if (lane == 0)
+        for (int i = 0; i < ST_N; ++i) g_stamp_buf[((size_t)blockIdx.x * 8 + wave) * ST_N + i] = st_acc[i];
+#endif
 }
 
-int mlp_max_grid() {
+int mlp_cu_count() {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 256;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 256;
-    return cus;  // one 128 KiB-LDS workgroup per CU
+    return cus;
+}
+
+// Tile = 32 samples: two 65 KiB-LDS workgroups share a CU (4 waves/SIMD), so one workgroup's
+// gather / epilogue / barrier phases are covered by the other's MFMA phase.  Tile = 64 samples:
+// one workgroup per CU, half the weight traffic per sample.  PNYOLO_MLP_TILE=32 selects the former; 64 is the default (measured faster: r01 DESIGN.md).
+int mlp_tile_samples() {
+    static int tile = 0;
+    if (!tile) {
+        const char* e = getenv("PNYOLO_MLP_TILE");
+        tile = (e && atoi(e) == 32) ? 32 : 64;
+    }
+    return tile;
+}
+int mlp_max_grid() { return mlp_cu_count() * (mlp_tile_samples() == 32 ? 2 : 1); }
+size_t mlp_scratch_floats() { return (size_t)mlp_max_grid() * mlp_tile_samples() * HID; }
+
+template <int MT>
+static void launch_mlp_t(const MlpArgs& a, int grid, hipStream_t st) {
+    constexpr int lds = ACT_KG * 32 * MT * 16 + 32 * 32 * MT;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pny_mlp_kernel<MT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+#ifdef PNY_STAMP
+    static unsigned long long* dbuf = nullptr;
+    const size_t nst = (size_t)grid * 8 * ST_N;
+    if (!dbuf) {
+        (void)hipMalloc((void**)&dbuf, (size_t)1024 * 8 * ST_N * sizeof(unsigned long long));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &dbuf, sizeof(dbuf));
+    }
+    (void)hipMemsetAsync(dbuf, 0, nst * sizeof(unsigned long long), st);
+#endif
+    hipLaunchKernelGGL(pny_mlp_kernel<MT>, dim3(grid), dim3(MLP_THREADS), lds, st, a);
+#ifdef PNY_STAMP
+    {
+        std::vector<unsigned long long> hst(nst);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(hst.data(), dbuf, nst * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        double sum[ST_N] = {0};
+        for (size_t i = 0; i < nst; ++i) sum[i % ST_N] += (double)hst[i];
+        static const char* names[ST_N] = {"total", "gemm", "gather", "prologue", "store+sync", "hsum", "lin_out",
+                                          "(sync1", "write", "sync2)"};
+        fprintf(stderr, "[pny stamp] tile=%d tiles=%d grid=%d:", 32 * MT, a.n_tiles, grid);
+        for (int i = 0; i < ST_N; ++i) fprintf(stderr, " %s=%.1f%%", names[i], 100.0 * sum[i] / sum[0]);
+        fprintf(stderr, " (mean wave cycles %.3g)\n", sum[0] / (grid * 8.0));
+    }
+#endif
 }
 
 void launch_mlp(const MlpArgs& a, int grid, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pny_mlp_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS_BYTES);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(pny_mlp_kernel, dim3(grid), dim3(MLP_THREADS), MLP_LDS_BYTES, st, a);
+    if (mlp_tile_samples() == 32)
+        launch_mlp_t<1>(a, grid, st);
+    else
+        launch_mlp_t<2>(a, grid, st);
 }
 
 }  // namespace pny

@@ -10,13 +10,11 @@
 namespace pny {
 
 constexpr int HID = 512;        // d_hidden this build is specialised for
-constexpr int TM = 64;          // samples (GEMM columns) per workgroup tile
 constexpr int MLP_THREADS = 512;
 constexpr int MAX_BLOCKS = 8;
 constexpr int MAX_VIEWS = 16;
 constexpr int D_IN_PAD = 48;    // 42 inputs padded to a multiple of 8 (one MFMA k-group pair)
 constexpr int ACT_KG = 128;     // k-groups (4 features each) held by the LDS activation buffer
-constexpr int MLP_LDS_BYTES = ACT_KG * TM * 16 + 2048;  // activations + per-sample tap table
 
 // World->camera pose and intrinsics of one source view (reference models.py:74-87 buffers).
 struct Cam {
@@ -49,7 +47,7 @@ struct MlpArgs {
     const float* rays;
     const float* z;
     float* out;       // (n_points, d_out)
-    float* scratch;   // gridDim.x * TM * HID floats: cross-view running sum
+    float* scratch;   // gridDim.x * tile * HID floats: cross-view running sum
     long long n_points;
     int K;            // samples per ray (mode 1)
     int mode;
@@ -61,7 +59,9 @@ struct MlpArgs {
 };
 
 void launch_mlp(const MlpArgs& a, int grid, hipStream_t st);
-int mlp_max_grid();
+int mlp_max_grid();        // resident workgroups = persistent grid size
+int mlp_tile_samples();    // samples per workgroup tile (32 or 64)
+size_t mlp_scratch_floats();
 
 // render_kernels.hip
 void launch_sample_coarse(const float* rays, long long n, int kc, int lindisp, const float* u, uint64_t seed,

@@ -10,7 +10,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpnyolo.so")
+# PNYOLO_LIB selects a diagnostic build (tools/stamp_build.sh); the product is libpnyolo.so
+LIB_PATH = os.environ.get("PNYOLO_LIB") or os.path.join(_HERE, "libpnyolo.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 c_float_p = C.POINTER(C.c_float)
