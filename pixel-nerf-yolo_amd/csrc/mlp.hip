@@ -86,7 +86,6 @@ __device__ __forceinline__ void mfma_iter(f32x16 (&acc)[2][MT], const float4& a0
 // WDepth<MT> k-iterations of fragments in flight and runs ACROSS layer boundaries: while a GEMM
 // drains, the ring already fills with the head of the next layer's slice (WSeg next), so neither
 // the epilogue/barrier phase nor the head of a GEMM waits on memory.
-constexpr int WDEPTH_MAX = 4;
 template <int MT>
 struct WDepth {
     static constexpr int value = MT == 1 ? 2 : 4;  // 128-VGPR (tile 32) variant cannot afford 4
