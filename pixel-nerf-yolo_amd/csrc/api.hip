@@ -3,6 +3,7 @@
 // in the kernels (mlp.hip, render_kernels.hip, encoder.hip).
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -189,7 +190,7 @@ int pny_model_create(pny_model** out, const pny_model_desc* desc) {
     if (desc->combine_layer < 0) return fail(PNY_ERR_ARG, "pny_model_create: combine_layer < 0");
     if (desc->d_latent < 32 || desc->d_latent % 32) return fail(PNY_ERR_ARG, "pny_model_create: d_latent must be a positive multiple of 32");
     if (desc->d_out < 1 || desc->d_out > 64) return fail(PNY_ERR_ARG, "pny_model_create: d_out out of range [1,64]");
-    if (3 + 6 * desc->num_freqs + 3 > D_IN_PAD || desc->num_freqs < 0) return fail(PNY_ERR_ARG, "pny_model_create: num_freqs too large (d_in must be <= 48)");
+    if (3 + 6 * desc->num_freqs + 3 > D_IN_PAD || desc->num_freqs < 0) return fail(PNY_ERR_ARG, "pny_model_create: num_freqs too large (d_in must be <= 64)");
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
         return fail(PNY_ERR_NOGPU, "pny_model_create: no HIP device visible (this library has no CPU path)");
@@ -511,6 +512,14 @@ static int run_mlp(pny_scene* s, int mode, const float* xyz, const float* dirs, 
     const long long tiles = (n_points + tm - 1) / tm;
     if (tiles > 0x7fffffffll) return fail(PNY_ERR_ARG, "too many points for one launch");
     a.n_tiles = (int)tiles;
+    {
+        static int stagger = -1;
+        if (stagger < 0) {
+            const char* e = getenv("PNYOLO_STAGGER");
+            stagger = e ? atoi(e) : 0;
+        }
+        a.stagger = stagger;
+    }
     int grid = mlp_max_grid();
     if (tiles < grid) grid = (int)tiles;
     int rc;

@@ -45,15 +45,27 @@ __device__ __forceinline__ unsigned long long stamp_now() {
     __builtin_amdgcn_sched_barrier(0);
     return t;
 }
+// raw event trace of workgroup 0: [wave][event] timestamps (first TRACE_N events of the launch)
+constexpr int TRACE_N = 256;
+__device__ unsigned long long* g_trace_buf;
+__device__ __forceinline__ void trace_ev(int& n, int wave, int lane) {
+    if (blockIdx.x == 0 && n < TRACE_N) {
+        const unsigned long long t = stamp_now();
+        if (lane == 0) g_trace_buf[wave * TRACE_N + n] = t;
+    }
+    ++n;
+}
 #define ST_BEGIN() const unsigned long long st_t0_ = stamp_now()
 #define ST_END(cat) st_acc[cat] += stamp_now() - st_t0_
-#define ST_ARG , unsigned long long (&st_acc)[ST_N]
-#define ST_PASS , st_acc
+#define ST_ARG , unsigned long long (&st_acc)[ST_N], int& tr_n
+#define ST_PASS , st_acc, tr_n
+#define TRACE() trace_ev(tr_n, wave, lane)
 #else
 #define ST_BEGIN()
 #define ST_END(cat)
 #define ST_ARG
 #define ST_PASS
+#define TRACE()
 #endif
 
 // ---- accumulator <-> feature mapping of v_mfma_f32_32x32x2_f32 -------------------------------
@@ -88,7 +100,7 @@ __device__ __forceinline__ void mfma_iter(f32x16 (&acc)[2][MT], const float4& a0
 // the epilogue/barrier phase nor the head of a GEMM waits on memory.
 template <int MT>
 struct WDepth {
-    static constexpr int value = MT == 1 ? 2 : 4;  // 128-VGPR (tile 32) variant cannot afford 4
+    static constexpr int value = MT == 1 ? 2 : 4;  // 128-VGPR (tile 32) variant cannot afford more
 };
 
 struct WSeg {  // this wave's slice of one packed layer: fragment j of n-tile t at w[t][j * 64]
@@ -106,6 +118,9 @@ __device__ __forceinline__ WSeg wseg(const float* packed, int jtot, int j0, int 
 template <int D>
 struct WRing {
     float4 f[D][2];
+#ifdef PNY_EXP_ONELAYER
+    const float4* exp_base[2];
+#endif
 };
 
 template <int D>
@@ -118,46 +133,97 @@ __device__ __forceinline__ void ring_fill(WRing<D>& r, const WSeg& s) {
     }
 }
 
+// One 16-byte weight-fragment load.  PNY_WLOAD selects the cache policy (experiments: 1 = nt,
+// 2 = sc1 i.e. L1 bypass); the product build uses the default policy.
+__device__ __forceinline__ float4 wload(const float4* p) {
+#if defined(PNY_WLOAD) && PNY_WLOAD == 1
+    typedef float f32x4n __attribute__((ext_vector_type(4)));
+    const f32x4n v = __builtin_nontemporal_load(reinterpret_cast<const f32x4n*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#elif defined(PNY_WLOAD) && PNY_WLOAD == 2
+    float4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+#else
+    return *p;
+#endif
+}
+
 // acc += W_slice * act over segment `cur`; leaves the ring holding the first WDEPTH fragments of
-// `next`.  Activation fragments (LDS) run one iteration ahead.  sched_barrier pins the issue order
-// so the compiler cannot sink the loads back next to their uses (it did in the first build).
+// `next`.  Ring slots are STATIC: the loop is unrolled by the depth; slot d is consumed by the MFMAs
+// of k-iteration j+d, and slot d-1 (whose MFMAs were issued in the previous step, so no register is
+// still being read) is refilled with fragment j+d-1+WDEPTH *while* slot d's MFMAs issue.  (A rotating
+// ring makes the compiler copy registers that are destinations of in-flight loads, which costs an
+// s_waitcnt vmcnt(0) per iteration -- measured: 15 % MFMA-pipe idle inside the loop.)
+// sched_group_barrier spreads the step's loads / LDS reads / address arithmetic between the MFMAs
+// so a wave that is alone on its SIMD (its partner waiting at a barrier) still issues them in the
+// shadow of its own 64-cycle MFMAs instead of between MFMA blocks.
+// Every segment length is a multiple of the depth (K padded accordingly on the host).
+// Activation fragments (LDS) alternate between two static slots, one iteration ahead.
 template <int MT>
-__device__ __forceinline__ void gemm_run(f32x16 (&acc)[2][MT], WRing<WDepth<MT>::value>& r, const WSeg& cur, const WSeg& next,
-                                         const float4* __restrict__ act, int lane) {
+__device__ __forceinline__ void gemm_run(f32x16 (&acc)[2][MT], WRing<WDepth<MT>::value>& r, const WSeg& cur,
+                                         const WSeg& next, const float4* __restrict__ act, int lane) {
     constexpr int TMc = 32 * MT, WDEPTH = WDepth<MT>::value;
     const int m0 = lane & 31, hh = lane >> 5;
     const float4* bp = act + hh * TMc + m0;
     const int jn = cur.jn, jl = jn - 1;
-    float4 bc[MT], bn[MT];
+    float4 B[2][MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) bc[mt] = bp[32 * mt];
-    for (int j = 0; j < jn; ++j) {
-        int jj = j + WDEPTH;
+    for (int mt = 0; mt < MT; ++mt) B[0][mt] = bp[32 * mt];
+    for (int j = 0; j < jn; j += WDEPTH) {
+#pragma unroll
+        for (int d = 0; d < WDEPTH; ++d) {
+            const int jd = j + d;
+            const int j1 = (jd + 1 < jl) ? jd + 1 : jl;
+            __builtin_amdgcn_sched_barrier(0);
+            // refill the slot consumed one step ago: fragment (jd - 1) + WDEPTH of the stream
+            constexpr int kPrev = 0;
+            (void)kPrev;
+            const int dp = (d + WDEPTH - 1) % WDEPTH;
+            int jj = jd - 1 + WDEPTH;
 #ifdef PNY_EXP_NOWSTREAM  // timing-only experiment: no weight streaming (wrong results)
-        jj = 0;
+            jj = 0;
 #endif
-        const bool in_cur = jj < jn;
-        int jx = in_cur ? jj : jj - jn;
-        if (!in_cur && jx >= next.jn) jx = next.jn - 1;
-        const float4* s0 = in_cur ? cur.w[0] : next.w[0];
-        const float4* s1 = in_cur ? cur.w[1] : next.w[1];
-        const float4 q0 = s0[(size_t)jx * 64];
-        const float4 q1 = s1[(size_t)jx * 64];
-        const int j1 = (j + 1 < jl) ? j + 1 : jl;
+#ifdef PNY_EXP_SMALLFOOT  // timing-only experiment: same load rate, 16 KiB footprint per wave (wrong results)
+            jj &= 7;
+#endif
+            const bool in_cur = jj < jn;
+            const int jx = in_cur ? jj : jj - jn;  // next.jn >= WDEPTH, so jx is in range
+#ifdef PNY_EXP_ONELAYER  // timing-only experiment: every segment streams the SAME 1 MB layer (wrong results)
+            const float4* s0 = r.exp_base[0];
+            const float4* s1 = r.exp_base[1];
+#else
+            const float4* s0 = in_cur ? cur.w[0] : next.w[0];
+            const float4* s1 = in_cur ? cur.w[1] : next.w[1];
+#endif
+            if (jd > 0) {  // at jd == 0 the previous slot still holds fragment WDEPTH-1 of this segment
+                r.f[dp][0] = wload(s0 + (size_t)jx * 64);
+                r.f[dp][1] = wload(s1 + (size_t)jx * 64);
+            }
+#ifndef PNY_EXP_NOLDS
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) bn[mt] = bp[(2 * j1) * TMc + 32 * mt];
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_iter<MT>(acc, r.f[0][0], r.f[0][1], bc);
-        __builtin_amdgcn_sched_barrier(0);
+            for (int mt = 0; mt < MT; ++mt) B[(d + 1) & 1][mt] = bp[(2 * j1) * TMc + 32 * mt];
+#else  // timing-only experiment: no activation fragment reads in the loop (wrong results)
 #pragma unroll
-        for (int d = 0; d + 1 < WDEPTH; ++d) {
-            r.f[d][0] = r.f[d + 1][0];
-            r.f[d][1] = r.f[d + 1][1];
+            for (int mt = 0; mt < MT; ++mt) B[(d + 1) & 1][mt] = B[d & 1][mt];
+            (void)j1;
+#endif
+            mfma_iter<MT>(acc, r.f[d][0], r.f[d][1], B[d & 1]);
+            // issue pattern of the step: MFMA, then a few non-MFMA instructions, repeated
+#pragma unroll
+            for (int i = 0; i < 8 * MT; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     // 1 MFMA
+                if (i == 1 || i == 3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
+                if (i == 5 || i == 6) __builtin_amdgcn_sched_group_barrier(0x100, MT == 2 ? 1 : 1, 0);  // DS read
+                __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);                     // <= 3 VALU/SALU
+            }
         }
-        r.f[WDEPTH - 1][0] = q0;
-        r.f[WDEPTH - 1][1] = q1;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) bc[mt] = bn[mt];
+    }
+    // the last slot of the segment was consumed in the final step: refill it for `next`
+    {
+        constexpr int dl = WDEPTH - 1;
+        r.f[dl][0] = wload(next.w[0] + (size_t)dl * 64);
+        r.f[dl][1] = wload(next.w[1] + (size_t)dl * 64);
     }
 }
 
@@ -261,12 +327,15 @@ __device__ __forceinline__ void res_block(f32x16 (&h)[2][MT], WRing<WDepth<MT>::
         __builtin_amdgcn_sched_barrier(0);
 #ifdef PNY_STAMP
         const unsigned long long f0 = stamp_now();
+        TRACE();  // ev A: arrive at sync1 (end of previous GEMM)
         __syncthreads();
         const unsigned long long f1 = stamp_now();
+        TRACE();  // ev B: past sync1
         store_relu(h, act, wave, lane);
         const unsigned long long f2 = stamp_now();
         __syncthreads();
         const unsigned long long f3 = stamp_now();
+        TRACE();  // ev C: past sync2 (GEMM fc0 starts)
         st_acc[ST_SYNC1] += f1 - f0;
         st_acc[ST_WRITE] += f2 - f1;
         st_acc[ST_SYNC2] += f3 - f2;
@@ -282,6 +351,7 @@ __device__ __forceinline__ void res_block(f32x16 (&h)[2][MT], WRing<WDepth<MT>::
         ST_BEGIN();
         gemm_run(net, ring, s_fc0, s_fc1, act, lane);
         ST_END(ST_GEMM);
+        TRACE();  // ev D: end of GEMM fc0
     }
     {
         ST_BEGIN();
@@ -460,6 +530,7 @@ __global__ __launch_bounds__(MLP_THREADS, MT == 1 ? 4 : 2) void pny_mlp_kernel(c
     const int jz_tot = a.L / 8;
 #ifdef PNY_STAMP
     unsigned long long st_acc[ST_N];
+    int tr_n = 0;
     for (int i = 0; i < ST_N; ++i) st_acc[i] = 0;
     const unsigned long long st_start = stamp_now();
 #endif
@@ -478,8 +549,24 @@ __global__ __launch_bounds__(MLP_THREADS, MT == 1 ? 4 : 2) void pny_mlp_kernel(c
         if (n_view_blocks < a.n_blocks) return wseg(a.w.w_fc0[n_view_blocks], 64, 0, 64, wave, lane);
         return s_in;  // next tile
     };
+    // De-synchronise the workgroups that share an XCD (blocks b, b+8, b+16, ... under round-robin
+    // dispatch; a speed heuristic only): if all 32 CUs touch every cold weight line at the same
+    // moment, each L2 miss becomes a 32-deep hit-on-miss pile-up.  Staggered, one CU takes the miss
+    // and the others find the line resident.
+    if (a.stagger > 0) {
+        const long long wait = (long long)((blockIdx.x >> 3) & 31) * a.stagger;
+        const long long t0 = __builtin_amdgcn_s_memtime();
+        while ((long long)__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
     WRing<WDepth<MT>::value> ring;
     ring_fill(ring, s_in);
+#ifdef PNY_EXP_ONELAYER
+    {
+        const WSeg e = wseg(a.w.w_fc0[0], 64, 0, 64, wave, lane);
+        ring.exp_base[0] = e.w[0];
+        ring.exp_base[1] = e.w[1];
+    }
+#endif
 
     for (long long tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         f32x16 h[2][MT];
@@ -628,6 +715,12 @@ static void launch_mlp_t(const MlpArgs& a, int grid, hipStream_t st) {
         (void)hipMalloc((void**)&dbuf, (size_t)1024 * 8 * ST_N * sizeof(unsigned long long));
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &dbuf, sizeof(dbuf));
     }
+    static unsigned long long* tbuf = nullptr;
+    if (!tbuf) {
+        (void)hipMalloc((void**)&tbuf, (size_t)8 * TRACE_N * sizeof(unsigned long long));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace_buf), &tbuf, sizeof(tbuf));
+    }
+    (void)hipMemsetAsync(tbuf, 0, (size_t)8 * TRACE_N * sizeof(unsigned long long), st);
     (void)hipMemsetAsync(dbuf, 0, nst * sizeof(unsigned long long), st);
 #endif
     hipLaunchKernelGGL(pny_mlp_kernel<MT>, dim3(grid), dim3(MLP_THREADS), lds, st, a);
@@ -643,6 +736,18 @@ static void launch_mlp_t(const MlpArgs& a, int grid, hipStream_t st) {
         fprintf(stderr, "[pny stamp] tile=%d tiles=%d grid=%d:", 32 * MT, a.n_tiles, grid);
         for (int i = 0; i < ST_N; ++i) fprintf(stderr, " %s=%.1f%%", names[i], 100.0 * sum[i] / sum[0]);
         fprintf(stderr, " (mean wave cycles %.3g)\n", sum[0] / (grid * 8.0));
+        if (const char* tf = getenv("PNYOLO_TRACE_FILE")) {
+            std::vector<unsigned long long> tr((size_t)8 * TRACE_N);
+            (void)hipMemcpy(tr.data(), tbuf, tr.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            if (FILE* f = fopen(tf, "a")) {
+                for (int w = 0; w < 8; ++w) {
+                    for (int e = 0; e < TRACE_N; ++e) fprintf(f, "%llu ", tr[(size_t)w * TRACE_N + e]);
+                    fprintf(f, "\n");
+                }
+                fprintf(f, "#\n");
+                fclose(f);
+            }
+        }
     }
 #endif
 }

@@ -13,7 +13,7 @@ constexpr int HID = 512;        // d_hidden this build is specialised for
 constexpr int MLP_THREADS = 512;
 constexpr int MAX_BLOCKS = 8;
 constexpr int MAX_VIEWS = 16;
-constexpr int D_IN_PAD = 48;    // 42 inputs padded to a multiple of 8 (one MFMA k-group pair)
+constexpr int D_IN_PAD = 64;    // 42 inputs padded to 8 k-iterations (a multiple of the weight-ring depth)
 constexpr int ACT_KG = 128;     // k-groups (4 features each) held by the LDS activation buffer
 
 // World->camera pose and intrinsics of one source view (reference models.py:74-87 buffers).
@@ -56,6 +56,7 @@ struct MlpArgs {
     float freq_factor;
     float sx, sy;     // latent_scaling / image_size (reference encoder.py:97)
     int n_tiles;
+    int stagger;      // start-up delay per XCD-local workgroup rank, in shader cycles (0 = off)
 };
 
 void launch_mlp(const MlpArgs& a, int grid, hipStream_t st);
