@@ -188,7 +188,7 @@ int pny_model_create(pny_model** out, const pny_model_desc* desc) {
     if (desc->d_hidden != HID) return fail(PNY_ERR_ARG, "pny_model_create: d_hidden must be 512");
     if (desc->n_blocks < 1 || desc->n_blocks > MAX_BLOCKS) return fail(PNY_ERR_ARG, "pny_model_create: n_blocks out of range [1,8]");
     if (desc->combine_layer < 0) return fail(PNY_ERR_ARG, "pny_model_create: combine_layer < 0");
-    if (desc->d_latent < 32 || desc->d_latent % 32) return fail(PNY_ERR_ARG, "pny_model_create: d_latent must be a positive multiple of 32");
+    if (desc->d_latent < 128 || desc->d_latent % 128) return fail(PNY_ERR_ARG, "pny_model_create: d_latent must be a positive multiple of 128");
     if (desc->d_out < 1 || desc->d_out > 64) return fail(PNY_ERR_ARG, "pny_model_create: d_out out of range [1,64]");
     if (3 + 6 * desc->num_freqs + 3 > D_IN_PAD || desc->num_freqs < 0) return fail(PNY_ERR_ARG, "pny_model_create: num_freqs too large (d_in must be <= 64)");
     int count = 0;

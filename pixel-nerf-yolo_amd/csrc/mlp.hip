@@ -1,5 +1,5 @@
 // Fused conditioned-MLP kernel for gfx950 (MI355X): everything PixelNeRFNet.forward does for a
-// tile of 64 query samples in ONE launch --
+// tile of query samples in ONE launch --
 //   world->camera transform, positional encoding, projection, bilinear latent gather
 //   (reference src/model/models.py:153-276, src/model/code.py:30-42, src/model/encoder.py:79-108),
 //   the ResnetFC chain with per-view latent injection and the cross-view mean
@@ -14,14 +14,17 @@
 //     the lane and 4 consecutive features per register quad, which is exactly the 16-byte
 //     k-group the next layer's B operand wants -> the epilogue is one ds_write_b128 per quad
 //     and no transposes or shuffles exist anywhere in the chain.
-//   * 8 waves per workgroup, wave w owns features [64w, 64w+64) of all 64 samples (2x2 tiles of
-//     32x32).  The residual stream h never leaves the accumulators (fc_1 accumulates straight
-//     into it); only relu(.) inputs travel through a 128 KiB LDS activation buffer.
-//   * the bilinear latent gather writes the lin_z B operand straight into that LDS buffer
-//     (channel-last latent, 16-byte loads, 128-byte lines per 8 lanes).
-//   * one workgroup per CU (LDS bound), persistent over tiles; cross-view running sum lives in
-//     a per-workgroup L2-resident scratch slab (128 KiB).
+//   * a workgroup owns a tile of samples x all 512 features; each wave owns a feature slice of all
+//     samples.  The residual stream h never leaves the accumulators (fc_1 accumulates straight
+//     into it); only relu(.) inputs travel through the LDS activation buffer.
+//   * the weights of all layers are one continuous stream per wave behind a static-slot register
+//     ring that runs across layer boundaries (see gemm_run).
+//   * the bilinear latent gather writes the lin_z B operand straight into the LDS buffer
+//     (channel-last latent, 16-byte loads, 128-byte lines per 8 lanes), chunk-pipelined with the GEMM.
+//   * persistent over tiles; the cross-view running sum lives in a per-workgroup slab accessed
+//     non-temporally.
 #include <cstdlib>
+#include <cstring>
 
 #include "pny_common.h"
 #ifdef PNY_STAMP
@@ -33,8 +36,25 @@ namespace pny {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Kernel shape: a workgroup owns a tile of TM = 32*MT samples x 512 features; wave w owns the NT
+// 32-feature n-tiles [NT*w, NT*w + NT) of all TM samples (NT x MT accumulator tiles of 32x32).
+//   <NT=2, MT=2>:  8 waves, 256 VGPRs, 2 waves/SIMD, 64-sample tile, one workgroup per CU
+//   <NT=1, MT=2>: 16 waves, 128 VGPRs, 4 waves/SIMD, 64-sample tile, one workgroup per CU
+//   <NT=2, MT=1>:  8 waves, 128 VGPRs, 4 waves/SIMD, 32-sample tile, two workgroups per CU
+template <int NT_, int MT_>
+struct Cfg {
+    static constexpr int NT = NT_, MT = MT_;
+    static constexpr int TM = 32 * MT;       // samples (GEMM columns) per workgroup tile
+    static constexpr int NW = 16 / NT;       // waves per workgroup
+    static constexpr int THREADS = 64 * NW;
+    static constexpr int WPS = (NT * MT == 4) ? 2 : 4;           // resident waves per SIMD (VGPR budget 512 / WPS)
+    static constexpr int WDEPTH = (NT == 2 && MT == 1) ? 2 : 4;  // weight-ring depth (k-iterations)
+    static constexpr int LDS = ACT_KG * TM * 16 + 32 * TM;       // activations + tap table
+};
+
 // Diagnostic build only (-DPNY_STAMP, tools/stamp_build.sh): s_memtime brackets around the phases
-// of a tile, summed per wave and dumped by launch_mlp.  No stamp executes in the product build.
+// of a tile, summed per wave and dumped by launch_mlp, plus a raw event trace of workgroup 0.
+// No stamp executes in the product build.
 #ifdef PNY_STAMP
 enum { ST_TOTAL = 0, ST_GEMM, ST_GATHER, ST_PROLOGUE, ST_STORE, ST_HSUM, ST_LINOUT, ST_SYNC1, ST_WRITE, ST_SYNC2, ST_N };
 __device__ unsigned long long* g_stamp_buf;
@@ -45,21 +65,26 @@ __device__ __forceinline__ unsigned long long stamp_now() {
     __builtin_amdgcn_sched_barrier(0);
     return t;
 }
-// raw event trace of workgroup 0: [wave][event] timestamps (first TRACE_N events of the launch)
 constexpr int TRACE_N = 256;
+constexpr int TRACE_WAVES = 16;
 __device__ unsigned long long* g_trace_buf;
-__device__ __forceinline__ void trace_ev(int& n, int wave, int lane) {
-    if (blockIdx.x == 0 && n < TRACE_N) {
+struct StampCtx {
+    unsigned long long acc[ST_N];
+    int tr_n;
+    int wave, lane;
+};
+__device__ __forceinline__ void trace_ev(StampCtx& c) {
+    if (blockIdx.x == 0 && c.tr_n < TRACE_N) {
         const unsigned long long t = stamp_now();
-        if (lane == 0) g_trace_buf[wave * TRACE_N + n] = t;
+        if (c.lane == 0) g_trace_buf[c.wave * TRACE_N + c.tr_n] = t;
     }
-    ++n;
+    ++c.tr_n;
 }
 #define ST_BEGIN() const unsigned long long st_t0_ = stamp_now()
-#define ST_END(cat) st_acc[cat] += stamp_now() - st_t0_
-#define ST_ARG , unsigned long long (&st_acc)[ST_N], int& tr_n
-#define ST_PASS , st_acc, tr_n
-#define TRACE() trace_ev(tr_n, wave, lane)
+#define ST_END(cat) st.acc[cat] += stamp_now() - st_t0_
+#define ST_ARG , StampCtx& st
+#define ST_PASS , st
+#define TRACE() trace_ev(st)
 #else
 #define ST_BEGIN()
 #define ST_END(cat)
@@ -70,21 +95,19 @@ __device__ __forceinline__ void trace_ev(int& n, int wave, int lane) {
 
 // ---- accumulator <-> feature mapping of v_mfma_f32_32x32x2_f32 -------------------------------
 // lane l = 32*hh + m0.  acc[nt][mt] register r holds
-//     feature n = 64*wave + 32*nt + 8*(r>>2) + 4*hh + (r&3),  sample m = 32*mt + m0.
+//     feature n = 32*NT*wave + 32*nt + 8*(r>>2) + 4*hh + (r&3),  sample m = 32*mt + m0.
 // LDS activation buffer: float4 act[kg][m], kg = feature/4, component = feature%4.
 // B operand of k-iteration j (8 features): lane reads act[2j + hh][m]; its 4 components feed 4
 // successive MFMAs.  A operand: packed so that lane reads float4 #lane of block (nt, j) holding
 //     W[32*nt_global + m0][8j + 4hh + 0..3].
 
-// One k-iteration (8 input features = 4 MFMA k-steps) of the wave's 2 x MT tile.
-template <int MT>
-__device__ __forceinline__ void mfma_iter(f32x16 (&acc)[2][MT], const float4& a0, const float4& a1,
-                                          const float4 (&b)[MT]) {
-#define PNY_STEP(c)                                                                                  \
-    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                \
-        acc[0][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c, b[mt].c, acc[0][mt], 0, 0, 0);       \
-    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                \
-        acc[1][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c, b[mt].c, acc[1][mt], 0, 0, 0);
+// One k-iteration (8 input features = 4 MFMA k-steps) of the wave's NT x MT tile.
+template <int NT, int MT>
+__device__ __forceinline__ void mfma_iter(f32x16 (&acc)[NT][MT], const float4 (&a)[NT], const float4 (&b)[MT]) {
+#define PNY_STEP(c)                                                                                   \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                 \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                             \
+            acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nt].c, b[mt].c, acc[nt][mt], 0, 0, 0);
     PNY_STEP(x)
     PNY_STEP(y)
     PNY_STEP(z)
@@ -94,59 +117,37 @@ __device__ __forceinline__ void mfma_iter(f32x16 (&acc)[2][MT], const float4& a0
 
 // The weights of all layers form ONE stream per wave: 13.7 MB per MLP cannot stay in the XCD's
 // 4 MiB L2, and the 32 CUs of an XCD reach a layer together, so the first touch of every line is an
-// Infinity-Cache access (~3 us under load) for everybody.  A register ring therefore keeps the next
-// WDepth<MT> k-iterations of fragments in flight and runs ACROSS layer boundaries: while a GEMM
-// drains, the ring already fills with the head of the next layer's slice (WSeg next), so neither
-// the epilogue/barrier phase nor the head of a GEMM waits on memory.
-template <int MT>
-struct WDepth {
-    static constexpr int value = MT == 1 ? 2 : 4;  // 128-VGPR (tile 32) variant cannot afford more
-};
-
-struct WSeg {  // this wave's slice of one packed layer: fragment j of n-tile t at w[t][j * 64]
-    const float4* w[2];
+// Infinity-Cache access for everybody.  A register ring keeps the next WDEPTH k-iterations of
+// fragments in flight and runs ACROSS layer boundaries: while a GEMM drains, the ring already fills
+// with the head of the next layer's slice (WSeg next), so neither the epilogue/barrier phase nor the
+// head of a GEMM waits on memory.
+struct WSeg {  // this wave's slice of one packed layer: fragment j of its n-tile t at w[(t*jtot + j)*64]
+    const float4* w;
+    int jtot;
     int jn;
 };
+template <int NT>
 __device__ __forceinline__ WSeg wseg(const float* packed, int jtot, int j0, int jn, int wave, int lane) {
     WSeg s;
-    s.w[0] = reinterpret_cast<const float4*>(packed) + ((size_t)(2 * wave) * jtot + j0) * 64 + lane;
-    s.w[1] = s.w[0] + (size_t)jtot * 64;
+    s.w = reinterpret_cast<const float4*>(packed) + ((size_t)(NT * wave) * jtot + j0) * 64 + lane;
+    s.jtot = jtot;
     s.jn = jn;
     return s;
 }
 
-template <int D>
+template <int D, int NT>
 struct WRing {
-    float4 f[D][2];
-#ifdef PNY_EXP_ONELAYER
-    const float4* exp_base[2];
-#endif
+    float4 f[D][NT];
 };
 
-template <int D>
-__device__ __forceinline__ void ring_fill(WRing<D>& r, const WSeg& s) {
+template <int D, int NT>
+__device__ __forceinline__ void ring_fill(WRing<D, NT>& r, const WSeg& s) {
 #pragma unroll
     for (int d = 0; d < D; ++d) {
         const int j = d < s.jn ? d : s.jn - 1;
-        r.f[d][0] = s.w[0][(size_t)j * 64];
-        r.f[d][1] = s.w[1][(size_t)j * 64];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) r.f[d][nt] = s.w[((size_t)nt * s.jtot + j) * 64];
     }
-}
-
-// One 16-byte weight-fragment load.  PNY_WLOAD selects the cache policy (experiments: 1 = nt,
-// 2 = sc1 i.e. L1 bypass); the product build uses the default policy.
-__device__ __forceinline__ float4 wload(const float4* p) {
-#if defined(PNY_WLOAD) && PNY_WLOAD == 1
-    typedef float f32x4n __attribute__((ext_vector_type(4)));
-    const f32x4n v = __builtin_nontemporal_load(reinterpret_cast<const f32x4n*>(p));
-    return make_float4(v.x, v.y, v.z, v.w);
-#elif defined(PNY_WLOAD) && PNY_WLOAD == 2
-    float4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-    return v;
-#else
-    return *p;
-#endif
 }
 
 // acc += W_slice * act over segment `cur`; leaves the ring holding the first WDEPTH fragments of
@@ -160,10 +161,10 @@ __device__ __forceinline__ float4 wload(const float4* p) {
 // shadow of its own 64-cycle MFMAs instead of between MFMA blocks.
 // Every segment length is a multiple of the depth (K padded accordingly on the host).
 // Activation fragments (LDS) alternate between two static slots, one iteration ahead.
-template <int MT>
-__device__ __forceinline__ void gemm_run(f32x16 (&acc)[2][MT], WRing<WDepth<MT>::value>& r, const WSeg& cur,
+template <class C>
+__device__ __forceinline__ void gemm_run(f32x16 (&acc)[C::NT][C::MT], WRing<C::WDEPTH, C::NT>& r, const WSeg& cur,
                                          const WSeg& next, const float4* __restrict__ act, int lane) {
-    constexpr int TMc = 32 * MT, WDEPTH = WDepth<MT>::value;
+    constexpr int NT = C::NT, MT = C::MT, TMc = C::TM, WDEPTH = C::WDEPTH;
     const int m0 = lane & 31, hh = lane >> 5;
     const float4* bp = act + hh * TMc + m0;
     const int jn = cur.jn, jl = jn - 1;
@@ -177,75 +178,58 @@ __device__ __forceinline__ void gemm_run(f32x16 (&acc)[2][MT], WRing<WDepth<MT>:
             const int j1 = (jd + 1 < jl) ? jd + 1 : jl;
             __builtin_amdgcn_sched_barrier(0);
             // refill the slot consumed one step ago: fragment (jd - 1) + WDEPTH of the stream
-            constexpr int kPrev = 0;
-            (void)kPrev;
             const int dp = (d + WDEPTH - 1) % WDEPTH;
-            int jj = jd - 1 + WDEPTH;
-#ifdef PNY_EXP_NOWSTREAM  // timing-only experiment: no weight streaming (wrong results)
-            jj = 0;
-#endif
-#ifdef PNY_EXP_SMALLFOOT  // timing-only experiment: same load rate, 16 KiB footprint per wave (wrong results)
-            jj &= 7;
-#endif
+            const int jj = jd - 1 + WDEPTH;
             const bool in_cur = jj < jn;
             const int jx = in_cur ? jj : jj - jn;  // next.jn >= WDEPTH, so jx is in range
-#ifdef PNY_EXP_ONELAYER  // timing-only experiment: every segment streams the SAME 1 MB layer (wrong results)
-            const float4* s0 = r.exp_base[0];
-            const float4* s1 = r.exp_base[1];
-#else
-            const float4* s0 = in_cur ? cur.w[0] : next.w[0];
-            const float4* s1 = in_cur ? cur.w[1] : next.w[1];
-#endif
+            const float4* src = in_cur ? cur.w : next.w;
+            const int sj = in_cur ? cur.jtot : next.jtot;
             if (jd > 0) {  // at jd == 0 the previous slot still holds fragment WDEPTH-1 of this segment
-                r.f[dp][0] = wload(s0 + (size_t)jx * 64);
-                r.f[dp][1] = wload(s1 + (size_t)jx * 64);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) r.f[dp][nt] = src[((size_t)nt * sj + jx) * 64];
             }
-#ifndef PNY_EXP_NOLDS
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) B[(d + 1) & 1][mt] = bp[(2 * j1) * TMc + 32 * mt];
-#else  // timing-only experiment: no activation fragment reads in the loop (wrong results)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) B[(d + 1) & 1][mt] = B[d & 1][mt];
-            (void)j1;
-#endif
-            mfma_iter<MT>(acc, r.f[d][0], r.f[d][1], B[d & 1]);
+            mfma_iter<NT, MT>(acc, r.f[d], B[d & 1]);
             // issue pattern of the step: MFMA, then a few non-MFMA instructions, repeated
 #pragma unroll
-            for (int i = 0; i < 8 * MT; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     // 1 MFMA
+            for (int i = 0; i < 4 * NT * MT; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        // 1 MFMA
                 if (i == 1 || i == 3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
-                if (i == 5 || i == 6) __builtin_amdgcn_sched_group_barrier(0x100, MT == 2 ? 1 : 1, 0);  // DS read
-                __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);                     // <= 3 VALU/SALU
+                if (i == 5 || i == 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+                __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);                        // <= 3 VALU/SALU
             }
         }
     }
     // the last slot of the segment was consumed in the final step: refill it for `next`
     {
         constexpr int dl = WDEPTH - 1;
-        r.f[dl][0] = wload(next.w[0] + (size_t)dl * 64);
-        r.f[dl][1] = wload(next.w[1] + (size_t)dl * 64);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) r.f[dl][nt] = next.w[((size_t)nt * next.jtot + dl) * 64];
     }
 }
 
-// A lane's slice of a 512-entry bias: features 64*wave + 32*nt + 8*q + 4*hh + 0..3.  Loaded before
-// a barrier phase (bias_load) and applied after it, so its latency is not exposed either.
+// A lane's slice of a 512-entry bias: features 32*NT*wave + 32*nt + 8*q + 4*hh + 0..3.  Loaded
+// before a barrier phase (bias_load) and applied after it, so its latency is not exposed.
+template <int NT>
 struct BiasRegs {
-    float4 v[2][4];
+    float4 v[NT][4];
 };
 
-__device__ __forceinline__ void bias_load(BiasRegs& b, const float* __restrict__ bias, int wave, int lane) {
+template <int NT>
+__device__ __forceinline__ void bias_load(BiasRegs<NT>& b, const float* __restrict__ bias, int wave, int lane) {
     const int hh = lane >> 5;
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            b.v[nt][q] = *reinterpret_cast<const float4*>(bias + 64 * wave + 32 * nt + 8 * q + 4 * hh);
+            b.v[nt][q] = *reinterpret_cast<const float4*>(bias + 32 * NT * wave + 32 * nt + 8 * q + 4 * hh);
 }
 
-template <int MT, bool ADD>
-__device__ __forceinline__ void bias_apply(f32x16 (&acc)[2][MT], const BiasRegs& b) {
+template <int NT, int MT, bool ADD>
+__device__ __forceinline__ void bias_apply(f32x16 (&acc)[NT][MT], const BiasRegs<NT>& b) {
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -265,12 +249,12 @@ __device__ __forceinline__ void bias_apply(f32x16 (&acc)[2][MT], const BiasRegs&
 }
 
 // act[feature/4][m] = relu(acc): the next layer's B operand.
-template <int MT>
-__device__ __forceinline__ void store_relu(const f32x16 (&acc)[2][MT], float4* __restrict__ act, int wave, int lane) {
+template <int NT, int MT>
+__device__ __forceinline__ void store_relu(const f32x16 (&acc)[NT][MT], float4* __restrict__ act, int wave, int lane) {
     constexpr int TMc = 32 * MT;
     const int m0 = lane & 31, hh = lane >> 5;
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -280,7 +264,7 @@ __device__ __forceinline__ void store_relu(const f32x16 (&acc)[2][MT], float4* _
                 v.y = fmaxf(acc[nt][mt][4 * q + 1], 0.f);
                 v.z = fmaxf(acc[nt][mt][4 * q + 2], 0.f);
                 v.w = fmaxf(acc[nt][mt][4 * q + 3], 0.f);
-                const int kg = 16 * wave + 8 * nt + 2 * q + hh;
+                const int kg = 8 * NT * wave + 8 * nt + 2 * q + hh;
                 act[kg * TMc + 32 * mt + m0] = v;
             }
 }
@@ -288,19 +272,19 @@ __device__ __forceinline__ void store_relu(const f32x16 (&acc)[2][MT], float4* _
 // Cross-view running sum slab (per workgroup, coalesced: register r of lane l at [r][l]).  It is
 // written and read with non-temporal accesses: 32 CUs x 128 KiB would otherwise evict the layer
 // weights from the XCD's 4 MiB L2 three times per tile.
-template <int MT>
-__device__ __forceinline__ void slab_store(const f32x16 (&h)[2][MT], float* slab) {
+template <int NT, int MT>
+__device__ __forceinline__ void slab_store(const f32x16 (&h)[NT][MT], float* slab) {
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(h[nt][mt][r], slab + ((nt * MT + mt) * 16 + r) * 64);
 }
-template <int MT>
-__device__ __forceinline__ void slab_load(f32x16 (&t)[2][MT], const float* slab) {
+template <int NT, int MT>
+__device__ __forceinline__ void slab_load(f32x16 (&t)[NT][MT], const float* slab) {
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -313,17 +297,18 @@ __device__ __forceinline__ void slab_load(f32x16 (&t)[2][MT], const float* slab)
 // `after` is the weight segment that follows this block in the stream.  With slab != nullptr the
 // other views' running sum is fetched into the (then dead) net registers underneath the fc_1
 // GEMM and added to h afterwards.
-template <int MT>
-__device__ __forceinline__ void res_block(f32x16 (&h)[2][MT], WRing<WDepth<MT>::value>& ring, const MlpWeights& w, int blk,
-                                          const WSeg& after, float4* act, int wave, int lane,
-                                          const float* slab ST_ARG) {
-    f32x16 net[2][MT];
-    BiasRegs bias;
-    const WSeg s_fc0 = wseg(w.w_fc0[blk], 64, 0, 64, wave, lane);
-    const WSeg s_fc1 = wseg(w.w_fc1[blk], 64, 0, 64, wave, lane);
+template <class C>
+__device__ __forceinline__ void res_block(f32x16 (&h)[C::NT][C::MT], WRing<C::WDEPTH, C::NT>& ring,
+                                          const MlpWeights& w, int blk, const WSeg& after, float4* act, int wave,
+                                          int lane, const float* slab ST_ARG) {
+    constexpr int NT = C::NT, MT = C::MT;
+    f32x16 net[NT][MT];
+    BiasRegs<NT> bias;
+    const WSeg s_fc0 = wseg<NT>(w.w_fc0[blk], 64, 0, 64, wave, lane);
+    const WSeg s_fc1 = wseg<NT>(w.w_fc1[blk], 64, 0, 64, wave, lane);
     {
         ST_BEGIN();
-        bias_load(bias, w.b_fc0[blk], wave, lane);
+        bias_load<NT>(bias, w.b_fc0[blk], wave, lane);
         __builtin_amdgcn_sched_barrier(0);
 #ifdef PNY_STAMP
         const unsigned long long f0 = stamp_now();
@@ -331,47 +316,47 @@ __device__ __forceinline__ void res_block(f32x16 (&h)[2][MT], WRing<WDepth<MT>::
         __syncthreads();
         const unsigned long long f1 = stamp_now();
         TRACE();  // ev B: past sync1
-        store_relu(h, act, wave, lane);
+        store_relu<NT, MT>(h, act, wave, lane);
         const unsigned long long f2 = stamp_now();
         __syncthreads();
         const unsigned long long f3 = stamp_now();
         TRACE();  // ev C: past sync2 (GEMM fc0 starts)
-        st_acc[ST_SYNC1] += f1 - f0;
-        st_acc[ST_WRITE] += f2 - f1;
-        st_acc[ST_SYNC2] += f3 - f2;
+        st.acc[ST_SYNC1] += f1 - f0;
+        st.acc[ST_WRITE] += f2 - f1;
+        st.acc[ST_SYNC2] += f3 - f2;
 #else
         __syncthreads();
-        store_relu(h, act, wave, lane);
+        store_relu<NT, MT>(h, act, wave, lane);
         __syncthreads();
 #endif
-        bias_apply<MT, false>(net, bias);
+        bias_apply<NT, MT, false>(net, bias);
         ST_END(ST_STORE);
     }
     {
         ST_BEGIN();
-        gemm_run(net, ring, s_fc0, s_fc1, act, lane);
+        gemm_run<C>(net, ring, s_fc0, s_fc1, act, lane);
         ST_END(ST_GEMM);
         TRACE();  // ev D: end of GEMM fc0
     }
     {
         ST_BEGIN();
-        bias_load(bias, w.b_fc1[blk], wave, lane);
+        bias_load<NT>(bias, w.b_fc1[blk], wave, lane);
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
-        store_relu(net, act, wave, lane);
-        if (slab) slab_load(net, slab);
+        store_relu<NT, MT>(net, act, wave, lane);
+        if (slab) slab_load<NT, MT>(net, slab);
         __syncthreads();
-        bias_apply<MT, true>(h, bias);
+        bias_apply<NT, MT, true>(h, bias);
         ST_END(ST_STORE);
     }
     {
         ST_BEGIN();
-        gemm_run(h, ring, s_fc1, after, act, lane);
+        gemm_run<C>(h, ring, s_fc1, after, act, lane);
         ST_END(ST_GEMM);
     }
     if (slab) {
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -399,7 +384,7 @@ __device__ __forceinline__ void load_point(const MlpArgs& a, long long s, float 
     }
 }
 
-// Positional-code entry e of the 48-row (42 valid) input column (reference code.py:30-42 layout:
+// Positional-code entry e of the 64-row (42 valid) input column (reference code.py:30-42 layout:
 // [x(3), then per frequency sin(f x)(3), sin(f x + pi/2)(3)], then view dirs (models.py:207)).
 __device__ __forceinline__ float input_entry(int e, const float (&xr)[3], const float (&vd)[3], float freq_factor,
                                              int num_freqs) {
@@ -416,12 +401,12 @@ __device__ __forceinline__ float input_entry(int e, const float (&xr)[3], const 
     return 0.f;
 }
 
-// Per (view, tile) prologue: B operand of lin_in into act k-groups 0..11, and the four bilinear
+// Per (view, tile) prologue: B operand of lin_in into act k-groups 0..15, and the four bilinear
 // taps of every sample into the tap table.
-template <int MT>
+template <class C>
 __device__ __forceinline__ void prologue(const MlpArgs& a, int v, long long tile, float4* act, int* tap_off,
                                          float* tap_w, int tid) {
-    constexpr int TMc = 32 * MT, NPART = MLP_THREADS / TMc;
+    constexpr int TMc = C::TM, NPART = C::THREADS / TMc;
     const int m = tid % TMc, part = tid / TMc;
     long long s = tile * TMc + m;
     if (s >= a.n_points) s = a.n_points - 1;
@@ -482,152 +467,178 @@ __device__ __forceinline__ void prologue(const MlpArgs& a, int v, long long tile
     }
 }
 
-// Bilinear gather of latent channels [c0, c0 + 4*nq) of view v for all samples of the tile into
-// the B-operand layout act[(c - c0)/4][m].  A wave pass covers 8 samples x 8 channel quads: the
-// lanes {l, l+8, .., l+56} read one 128-byte line per tap, each 8-lane group writes 128
-// contiguous LDS bytes.  A lane keeps the same sample for the whole gather, so its four tap
-// offsets / weights are read once and the loop body is 4 independent 16-byte loads per pass.
-template <int MT>
-__device__ __forceinline__ void gather_latent(const MlpArgs& a, int v, int c0, int nq, float4* act,
-                                              const int* tap_off, const float* tap_w, int wave, int lane) {
-    constexpr int TMc = 32 * MT, NMB = TMc / 8;  // sample blocks of 8
-    constexpr int QSTEP = 8 / NMB;               // q-blocks advanced per pass of the 8 waves
+// Bilinear gather of the latent (reference encoder.py:101 F.grid_sample, written tap by tap) into the
+// B-operand layout act[(c - c0)/4][m], pipelined with the lin_z GEMM in chunks of GCH channels:
+// gather_issue() starts the 16-byte tap loads of a chunk into registers, gather_commit() combines
+// the four taps and writes the chunk to its LDS window.  The loads of chunk c+1 are issued before the
+// MFMAs of chunk c (the registers are the then-dead `net` accumulators' budget); because vmcnt
+// retires in order, the first ring wait of that GEMM still covers them, so about one ring period of
+// their latency hides.
+// A wave pass covers 8 samples x 8 channel quads: the lanes {l, l+8, .., l+56} read one 128-byte
+// line per tap, each 8-lane group writes 128 contiguous LDS bytes.  A lane keeps the same sample for
+// the whole gather, so its four tap pointers / weights are set up once per (view, block).
+constexpr int GCH = 128;  // channels per gather chunk = 16 k-iterations of the lin_z GEMM
+
+template <class C>
+struct GatherTaps {
+    static constexpr int NMB = C::TM / 8;           // sample blocks of 8
+    static constexpr int QSTEP = C::NW / NMB;       // q-blocks (32 channels) covered per pass of all waves
+    static constexpr int QPW = (GCH / 32) / QSTEP;  // q-blocks per wave per chunk
+    static_assert(QSTEP >= 1 && QPW >= 1 && QPW * QSTEP * 32 == GCH, "gather mapping");
+    const float* t[4];  // tap base pointers (view, pixel, + 4*ql), channel 0
+    float w[4];
+    float4 x[QPW][4];
+};
+
+template <class C>
+__device__ __forceinline__ void gather_setup(GatherTaps<C>& g, const MlpArgs& a, int v, const int* tap_off,
+                                             const float* tap_w, int wave, int lane) {
+    constexpr int TMc = C::TM, NMB = GatherTaps<C>::NMB;
     const int m = (wave % NMB) * 8 + (lane & 7);
-    const int ql = lane >> 3;
-    const float* base = a.latent + (size_t)v * a.Hl * a.Wl * a.L + c0 + 4 * ql;
-    const float* t0 = base + tap_off[0 * TMc + m];
-    const float* t1 = base + tap_off[1 * TMc + m];
-    const float* t2 = base + tap_off[2 * TMc + m];
-    const float* t3 = base + tap_off[3 * TMc + m];
-    const float w0 = tap_w[0 * TMc + m], w1 = tap_w[1 * TMc + m], w2 = tap_w[2 * TMc + m], w3 = tap_w[3 * TMc + m];
-    float4* dst = act + ql * TMc + m;
-    const int nqb = nq >> 3;
-#pragma unroll 4
-    for (int qb = wave / NMB; qb < nqb; qb += QSTEP) {
-        const float4 x0 = *reinterpret_cast<const float4*>(t0 + 32 * qb);
-        const float4 x1 = *reinterpret_cast<const float4*>(t1 + 32 * qb);
-        const float4 x2 = *reinterpret_cast<const float4*>(t2 + 32 * qb);
-        const float4 x3 = *reinterpret_cast<const float4*>(t3 + 32 * qb);
+    const float* base = a.latent + (size_t)v * a.Hl * a.Wl * a.L + 4 * (lane >> 3);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        g.t[k] = base + tap_off[k * TMc + m];
+        g.w[k] = tap_w[k * TMc + m];
+    }
+}
+
+template <class C>
+__device__ __forceinline__ void gather_issue(GatherTaps<C>& g, int c0, int wave) {
+    constexpr int NMB = GatherTaps<C>::NMB, QSTEP = GatherTaps<C>::QSTEP;
+#pragma unroll
+    for (int i = 0; i < GatherTaps<C>::QPW; ++i) {
+        const int qb = wave / NMB + i * QSTEP;  // q-block (8 quads = 32 channels) within the chunk
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g.x[i][k] = *reinterpret_cast<const float4*>(g.t[k] + c0 + 32 * qb);
+    }
+}
+
+template <class C>
+__device__ __forceinline__ void gather_commit(const GatherTaps<C>& g, float4* act_win, int wave, int lane) {
+    constexpr int TMc = C::TM, NMB = GatherTaps<C>::NMB, QSTEP = GatherTaps<C>::QSTEP;
+    const int m = (wave % NMB) * 8 + (lane & 7);
+    float4* dst = act_win + (lane >> 3) * TMc + m;
+#pragma unroll
+    for (int i = 0; i < GatherTaps<C>::QPW; ++i) {
+        const int qb = wave / NMB + i * QSTEP;
         float4 r;  // ATen order: nw*w + ne*w + sw*w + se*w
-        r.x = ((x0.x * w0 + x1.x * w1) + x2.x * w2) + x3.x * w3;
-        r.y = ((x0.y * w0 + x1.y * w1) + x2.y * w2) + x3.y * w3;
-        r.z = ((x0.z * w0 + x1.z * w1) + x2.z * w2) + x3.z * w3;
-        r.w = ((x0.w * w0 + x1.w * w1) + x2.w * w2) + x3.w * w3;
+        r.x = ((g.x[i][0].x * g.w[0] + g.x[i][1].x * g.w[1]) + g.x[i][2].x * g.w[2]) + g.x[i][3].x * g.w[3];
+        r.y = ((g.x[i][0].y * g.w[0] + g.x[i][1].y * g.w[1]) + g.x[i][2].y * g.w[2]) + g.x[i][3].y * g.w[3];
+        r.z = ((g.x[i][0].z * g.w[0] + g.x[i][1].z * g.w[1]) + g.x[i][2].z * g.w[2]) + g.x[i][3].z * g.w[3];
+        r.w = ((g.x[i][0].w * g.w[0] + g.x[i][1].w * g.w[1]) + g.x[i][2].w * g.w[2]) + g.x[i][3].w * g.w[3];
         dst[(size_t)(8 * qb) * TMc] = r;
     }
 }
 
-template <int MT>
-__global__ __launch_bounds__(MLP_THREADS, MT == 1 ? 4 : 2) void pny_mlp_kernel(const MlpArgs a) {
-    constexpr int TMc = 32 * MT;
+template <class C>
+__global__ __launch_bounds__(C::THREADS, C::WPS) void pny_mlp_kernel(const MlpArgs a) {
+    constexpr int NT = C::NT, MT = C::MT, TMc = C::TM;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float4* act = reinterpret_cast<float4*>(smem_raw);
     int* tap_off = reinterpret_cast<int*>(smem_raw + ACT_KG * TMc * 16);
     float* tap_w = reinterpret_cast<float*>(smem_raw + ACT_KG * TMc * 16 + 16 * TMc);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float* slab = a.scratch + (size_t)blockIdx.x * (TMc * HID) + (size_t)wave * (2 * MT * 16 * 64) + lane;
+    float* slab = a.scratch + (size_t)blockIdx.x * (TMc * HID) + (size_t)wave * (NT * MT * 16 * 64) + lane;
     const int jz_tot = a.L / 8;
 #ifdef PNY_STAMP
-    unsigned long long st_acc[ST_N];
-    int tr_n = 0;
-    for (int i = 0; i < ST_N; ++i) st_acc[i] = 0;
+    StampCtx st;
+    st.tr_n = 0;
+    st.wave = wave;
+    st.lane = lane;
+    for (int i = 0; i < ST_N; ++i) st.acc[i] = 0;
     const unsigned long long st_start = stamp_now();
 #endif
 
     const int n_view_blocks = a.combine_layer < a.n_blocks ? a.combine_layer : a.n_blocks;
     // weight segments of the stream (this wave's slices), in execution order:
     //   per view: lin_in, then per view-block: lin_z chunks, fc_0, fc_1; then the post-combine blocks
-    const WSeg s_in = wseg(a.w.w_in, D_IN_PAD / 8, 0, D_IN_PAD / 8, wave, lane);
-    auto zseg = [&](int blk, int c0) {
-        const int nch = (a.L - c0) < 4 * ACT_KG ? (a.L - c0) : 4 * ACT_KG;
-        return wseg(a.w.w_z[blk], jz_tot, c0 / 8, nch / 8, wave, lane);
-    };
+    const WSeg s_in = wseg<NT>(a.w.w_in, D_IN_PAD / 8, 0, D_IN_PAD / 8, wave, lane);
+    auto zseg = [&](int blk, int c0) { return wseg<NT>(a.w.w_z[blk], jz_tot, c0 / 8, GCH / 8, wave, lane); };
+    auto fc0seg = [&](int blk) { return wseg<NT>(a.w.w_fc0[blk], 64, 0, 64, wave, lane); };
     // segment that follows the per-view part of view v (after its last view-block)
     auto after_view = [&](int v) {
         if (v + 1 < a.NS) return s_in;
-        if (n_view_blocks < a.n_blocks) return wseg(a.w.w_fc0[n_view_blocks], 64, 0, 64, wave, lane);
+        if (n_view_blocks < a.n_blocks) return fc0seg(n_view_blocks);
         return s_in;  // next tile
     };
-    // De-synchronise the workgroups that share an XCD (blocks b, b+8, b+16, ... under round-robin
-    // dispatch; a speed heuristic only): if all 32 CUs touch every cold weight line at the same
-    // moment, each L2 miss becomes a 32-deep hit-on-miss pile-up.  Staggered, one CU takes the miss
-    // and the others find the line resident.
-    if (a.stagger > 0) {
-        const long long wait = (long long)((blockIdx.x >> 3) & 31) * a.stagger;
-        const long long t0 = __builtin_amdgcn_s_memtime();
-        while ((long long)__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
-    }
-    WRing<WDepth<MT>::value> ring;
+    WRing<C::WDEPTH, NT> ring;
     ring_fill(ring, s_in);
-#ifdef PNY_EXP_ONELAYER
-    {
-        const WSeg e = wseg(a.w.w_fc0[0], 64, 0, 64, wave, lane);
-        ring.exp_base[0] = e.w[0];
-        ring.exp_base[1] = e.w[1];
-    }
-#endif
 
     for (long long tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-        f32x16 h[2][MT];
+        f32x16 h[NT][MT];
         for (int v = 0; v < a.NS; ++v) {
-            BiasRegs bias;
             {
+                BiasRegs<NT> bias;
                 ST_BEGIN();
-                bias_load(bias, a.w.b_in, wave, lane);  // b_in + b_z[0] (folded on the host)
+                bias_load<NT>(bias, a.w.b_in, wave, lane);  // b_in + b_z[0] (folded on the host)
                 __builtin_amdgcn_sched_barrier(0);
                 __syncthreads();
-                prologue<MT>(a, v, tile, act, tap_off, tap_w, tid);
+                prologue<C>(a, v, tile, act, tap_off, tap_w, tid);
                 __syncthreads();
-                bias_apply<MT, false>(h, bias);
+                bias_apply<NT, MT, false>(h, bias);
                 ST_END(ST_PROLOGUE);
             }
             {
                 ST_BEGIN();
-                gemm_run(h, ring, s_in, n_view_blocks > 0 ? zseg(0, 0) : after_view(v), act, lane);
+                gemm_run<C>(h, ring, s_in, n_view_blocks > 0 ? zseg(0, 0) : after_view(v), act, lane);
                 ST_END(ST_GEMM);
             }
             for (int blk = 0; blk < n_view_blocks; ++blk) {
-                // x = x + lin_z[blk](z)  (reference resnetfc.py:176-182); bias folded upstream
-                for (int c0 = 0; c0 < a.L; c0 += 4 * ACT_KG) {
-                    const int nch = (a.L - c0) < 4 * ACT_KG ? (a.L - c0) : 4 * ACT_KG;
+                // x = x + lin_z[blk](z)  (reference resnetfc.py:176-182); bias folded upstream.
+                // GCH-channel chunks: the taps of chunk c+1 load while the MFMAs of chunk c run; chunk c
+                // lives in LDS window c % 4 (a window is rewritten 4 chunks = 3 barriers later).
+                {
+                    GatherTaps<C> g;
                     {
                         ST_BEGIN();
-                        __syncthreads();
-                        gather_latent<MT>(a, v, c0, nch / 4, act, tap_off, tap_w, wave, lane);
-                        __syncthreads();
+                        gather_setup<C>(g, a, v, tap_off, tap_w, wave, lane);
+                        gather_issue<C>(g, 0, wave);
+                        __builtin_amdgcn_sched_barrier(0);
+                        __syncthreads();  // every wave is done reading the buffer (previous GEMM)
                         ST_END(ST_GATHER);
                     }
-                    ST_BEGIN();
-                    const bool more = c0 + 4 * ACT_KG < a.L;
-                    gemm_run(h, ring, zseg(blk, c0),
-                             more ? zseg(blk, c0 + 4 * ACT_KG) : wseg(a.w.w_fc0[blk], 64, 0, 64, wave, lane), act, lane);
-                    ST_END(ST_GEMM);
+                    for (int c0 = 0; c0 < a.L; c0 += GCH) {
+                        float4* win = act + (size_t)((c0 / GCH) & 3) * (GCH / 4) * TMc;
+                        const bool more = c0 + GCH < a.L;
+                        {
+                            ST_BEGIN();
+                            gather_commit<C>(g, win, wave, lane);
+                            if (more) gather_issue<C>(g, c0 + GCH, wave);
+                            __builtin_amdgcn_sched_barrier(0);
+                            __syncthreads();  // chunk visible to all waves
+                            ST_END(ST_GATHER);
+                        }
+                        ST_BEGIN();
+                        gemm_run<C>(h, ring, zseg(blk, c0), more ? zseg(blk, c0 + GCH) : fc0seg(blk), win, lane);
+                        ST_END(ST_GEMM);
+                    }
                 }
                 // the last per-view block also folds in the running sum over the views done so far
                 // (reference util.py:489-499 combine_interleaved, mean over the NS views)
                 const bool last = (blk == n_view_blocks - 1);
-                res_block<MT>(h, ring, a.w, blk, last ? after_view(v) : zseg(blk + 1, 0), act, wave, lane,
-                              (last && v > 0) ? slab : nullptr ST_PASS);
+                res_block<C>(h, ring, a.w, blk, last ? after_view(v) : zseg(blk + 1, 0), act, wave, lane,
+                             (last && v > 0) ? slab : nullptr ST_PASS);
             }
             if (a.NS > 1) {
                 ST_BEGIN();
                 if (n_view_blocks == 0 && v > 0) {  // degenerate combine_layer = 0: no block to hide the fetch under
-                    f32x16 t[2][MT];
-                    slab_load(t, slab);
+                    f32x16 t[NT][MT];
+                    slab_load<NT, MT>(t, slab);
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
+                    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                             for (int r = 0; r < 16; ++r) h[nt][mt][r] = t[nt][mt][r] + h[nt][mt][r];
                 }
                 if (v + 1 < a.NS) {
-                    slab_store(h, slab);
+                    slab_store<NT, MT>(h, slab);
                 } else {
                     const float ns = (float)a.NS;
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
+                    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -637,16 +648,15 @@ __global__ __launch_bounds__(MLP_THREADS, MT == 1 ? 4 : 2) void pny_mlp_kernel(c
             }
         }
         for (int blk = n_view_blocks; blk < a.n_blocks; ++blk)
-            res_block<MT>(h, ring, a.w, blk,
-                          blk + 1 < a.n_blocks ? wseg(a.w.w_fc0[blk + 1], 64, 0, 64, wave, lane) : s_in, act, wave, lane,
-                          nullptr ST_PASS);
+            res_block<C>(h, ring, a.w, blk, blk + 1 < a.n_blocks ? fc0seg(blk + 1) : s_in, act, wave, lane,
+                         nullptr ST_PASS);
 
         // out = lin_out(relu(h)) (reference resnetfc.py:185) + output head (models.py:312-317)
         ST_BEGIN();
         __syncthreads();
-        store_relu(h, act, wave, lane);
+        store_relu<NT, MT>(h, act, wave, lane);
         __syncthreads();
-        for (int idx = tid; idx < a.d_out * TMc; idx += MLP_THREADS) {
+        for (int idx = tid; idx < a.d_out * TMc; idx += C::THREADS) {
             const int o = idx / TMc, m = idx % TMc;
             const float4* wrow = reinterpret_cast<const float4*>(a.w.w_out + (size_t)o * HID);
             float sum = 0.f;
@@ -672,12 +682,13 @@ __global__ __launch_bounds__(MLP_THREADS, MT == 1 ? 4 : 2) void pny_mlp_kernel(c
         ST_END(ST_LINOUT);
     }
 #ifdef PNY_STAMP
-    st_acc[ST_TOTAL] = stamp_now() - st_start;
+    st.acc[ST_TOTAL] = stamp_now() - st_start;
     if (lane == 0)
-        for (int i = 0; i < ST_N; ++i) g_stamp_buf[((size_t)blockIdx.x * 8 + wave) * ST_N + i] = st_acc[i];
+        for (int i = 0; i < ST_N; ++i) g_stamp_buf[((size_t)blockIdx.x * C::NW + wave) * ST_N + i] = st.acc[i];
 #endif
 }
 
+// ------------------------------------------------------------------------------------- host side
 int mlp_cu_count() {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 256;
@@ -685,45 +696,46 @@ int mlp_cu_count() {
     return cus;
 }
 
-// Tile = 32 samples: two 65 KiB-LDS workgroups share a CU (4 waves/SIMD), so one workgroup's
-// gather / epilogue / barrier phases are covered by the other's MFMA phase.  Tile = 64 samples:
-// one workgroup per CU, half the weight traffic per sample.  PNYOLO_MLP_TILE=32 selects the former; 64 is the default (measured faster: r01 DESIGN.md).
-int mlp_tile_samples() {
-    static int tile = 0;
-    if (!tile) {
-        const char* e = getenv("PNYOLO_MLP_TILE");
-        tile = (e && atoi(e) == 32) ? 32 : 64;
+// PNYOLO_MLP_VARIANT selects the kernel shape: "8x64" (default), "16x64", "8x32" (see Cfg).
+enum MlpVariant { V_8x64 = 0, V_16x64 = 1, V_8x32 = 2 };
+static MlpVariant mlp_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("PNYOLO_MLP_VARIANT");
+        v = V_8x64;
+        if (e && !strcmp(e, "16x64")) v = V_16x64;
+        if (e && !strcmp(e, "8x32")) v = V_8x32;
     }
-    return tile;
+    return (MlpVariant)v;
 }
-int mlp_max_grid() { return mlp_cu_count() * (mlp_tile_samples() == 32 ? 2 : 1); }
+int mlp_tile_samples() { return mlp_variant() == V_8x32 ? 32 : 64; }
+int mlp_max_grid() { return mlp_cu_count() * (mlp_variant() == V_8x32 ? 2 : 1); }
 size_t mlp_scratch_floats() { return (size_t)mlp_max_grid() * mlp_tile_samples() * HID; }
 
-template <int MT>
+template <class C>
 static void launch_mlp_t(const MlpArgs& a, int grid, hipStream_t st) {
-    constexpr int lds = ACT_KG * 32 * MT * 16 + 32 * 32 * MT;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pny_mlp_kernel<MT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pny_mlp_kernel<C>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
         attr_set = true;
     }
 #ifdef PNY_STAMP
     static unsigned long long* dbuf = nullptr;
-    const size_t nst = (size_t)grid * 8 * ST_N;
+    const size_t nst = (size_t)grid * C::NW * ST_N;
     if (!dbuf) {
-        (void)hipMalloc((void**)&dbuf, (size_t)1024 * 8 * ST_N * sizeof(unsigned long long));
+        (void)hipMalloc((void**)&dbuf, (size_t)1024 * 16 * ST_N * sizeof(unsigned long long));
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &dbuf, sizeof(dbuf));
     }
     static unsigned long long* tbuf = nullptr;
     if (!tbuf) {
-        (void)hipMalloc((void**)&tbuf, (size_t)8 * TRACE_N * sizeof(unsigned long long));
+        (void)hipMalloc((void**)&tbuf, (size_t)TRACE_WAVES * TRACE_N * sizeof(unsigned long long));
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace_buf), &tbuf, sizeof(tbuf));
     }
-    (void)hipMemsetAsync(tbuf, 0, (size_t)8 * TRACE_N * sizeof(unsigned long long), st);
+    (void)hipMemsetAsync(tbuf, 0, (size_t)TRACE_WAVES * TRACE_N * sizeof(unsigned long long), st);
     (void)hipMemsetAsync(dbuf, 0, nst * sizeof(unsigned long long), st);
 #endif
-    hipLaunchKernelGGL(pny_mlp_kernel<MT>, dim3(grid), dim3(MLP_THREADS), lds, st, a);
+    hipLaunchKernelGGL(pny_mlp_kernel<C>, dim3(grid), dim3(C::THREADS), C::LDS, st, a);
 #ifdef PNY_STAMP
     {
         std::vector<unsigned long long> hst(nst);
@@ -733,14 +745,14 @@ static void launch_mlp_t(const MlpArgs& a, int grid, hipStream_t st) {
         for (size_t i = 0; i < nst; ++i) sum[i % ST_N] += (double)hst[i];
         static const char* names[ST_N] = {"total", "gemm", "gather", "prologue", "store+sync", "hsum", "lin_out",
                                           "(sync1", "write", "sync2)"};
-        fprintf(stderr, "[pny stamp] tile=%d tiles=%d grid=%d:", 32 * MT, a.n_tiles, grid);
+        fprintf(stderr, "[pny stamp] waves=%d tile=%d tiles=%d grid=%d:", C::NW, C::TM, a.n_tiles, grid);
         for (int i = 0; i < ST_N; ++i) fprintf(stderr, " %s=%.1f%%", names[i], 100.0 * sum[i] / sum[0]);
-        fprintf(stderr, " (mean wave cycles %.3g)\n", sum[0] / (grid * 8.0));
+        fprintf(stderr, " (mean wave cycles %.3g)\n", sum[0] / ((double)grid * C::NW));
         if (const char* tf = getenv("PNYOLO_TRACE_FILE")) {
-            std::vector<unsigned long long> tr((size_t)8 * TRACE_N);
+            std::vector<unsigned long long> tr((size_t)TRACE_WAVES * TRACE_N);
             (void)hipMemcpy(tr.data(), tbuf, tr.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
             if (FILE* f = fopen(tf, "a")) {
-                for (int w = 0; w < 8; ++w) {
+                for (int w = 0; w < C::NW; ++w) {
                     for (int e = 0; e < TRACE_N; ++e) fprintf(f, "%llu ", tr[(size_t)w * TRACE_N + e]);
                     fprintf(f, "\n");
                 }
@@ -753,10 +765,11 @@ static void launch_mlp_t(const MlpArgs& a, int grid, hipStream_t st) {
 }
 
 void launch_mlp(const MlpArgs& a, int grid, hipStream_t st) {
-    if (mlp_tile_samples() == 32)
-        launch_mlp_t<1>(a, grid, st);
-    else
-        launch_mlp_t<2>(a, grid, st);
+    switch (mlp_variant()) {
+        case V_16x64: launch_mlp_t<Cfg<1, 2>>(a, grid, st); break;
+        case V_8x32: launch_mlp_t<Cfg<2, 1>>(a, grid, st); break;
+        default: launch_mlp_t<Cfg<2, 2>>(a, grid, st); break;
+    }
 }
 
 }  // namespace pny
