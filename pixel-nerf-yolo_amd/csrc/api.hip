@@ -512,14 +512,6 @@ static int run_mlp(pny_scene* s, int mode, const float* xyz, const float* dirs, 
     const long long tiles = (n_points + tm - 1) / tm;
     if (tiles > 0x7fffffffll) return fail(PNY_ERR_ARG, "too many points for one launch");
     a.n_tiles = (int)tiles;
-    {
-        static int stagger = -1;
-        if (stagger < 0) {
-            const char* e = getenv("PNYOLO_STAGGER");
-            stagger = e ? atoi(e) : 0;
-        }
-        a.stagger = stagger;
-    }
     int grid = mlp_max_grid();
     if (tiles < grid) grid = (int)tiles;
     int rc;

@@ -56,7 +56,6 @@ struct MlpArgs {
     float freq_factor;
     float sx, sy;     // latent_scaling / image_size (reference encoder.py:97)
     int n_tiles;
-    int stagger;      // start-up delay per XCD-local workgroup rank, in shader cycles (0 = off)
 };
 
 void launch_mlp(const MlpArgs& a, int grid, hipStream_t st);
