@@ -340,3 +340,166 @@ def test_full_frame_properties():
     with torch.no_grad():
         s2 = ren(net, pad)
     assert torch.equal(s1["fine"]["rgb"][0], s2["fine"]["rgb"][0, 37:237])
+
+
+# --------------------------------------------------------------------------- more configurations
+def small_scene(ns=2, H=32, W=40, seed=50, conf=None, per_view_intrinsics=False):
+    """A small seeded scene on both sides (HIP net + oracle Scene) for configuration sweeps."""
+    c = conf or pconf.default_mv()
+    net = make_model(c["model"]).eval()
+    mc, mf = c.d["model"]["mlp_coarse"], c.d["model"]["mlp_fine"]
+    nb, cl = mc.get("n_blocks", 5), mc.get("combine_layer", 1000)
+    sd_c = synth.mlp_state(seed + 1, n_blocks=nb, combine_layer=cl)
+    net.mlp_coarse.load_state_dict({k: torch.from_numpy(v) for k, v in sd_c.items()})
+    sd_f = None
+    if net.mlp_fine is not None:
+        sd_f = synth.mlp_state(seed + 2, n_blocks=mf.get("n_blocks", 5), combine_layer=mf.get("combine_layer", 1000))
+        net.mlp_fine.load_state_dict({k: torch.from_numpy(v) for k, v in sd_f.items()})
+    net = net.to(DEV)
+    src, tgt = synth.scene_cameras(ns)
+    lat = synth.latent(seed + 3, ns, 512, H // 2, W // 2)
+    if per_view_intrinsics:
+        focal = torch.tensor([[30.0 + 2 * i, 31.0 + i] for i in range(ns)])
+        cc = torch.tensor([[W * 0.5 + i, H * 0.5 - i] for i in range(ns)])
+    else:
+        focal, cc = torch.tensor(32.0), torch.tensor([[W * 0.5, H * 0.5]])
+    net.encode(torch.zeros(1, ns, 3, H, W), torch.from_numpy(src)[None], focal, c=cc, latent=torch.from_numpy(lat))
+    sc = orc.Scene(sd_c, sd_f, lat, src, focal, cc, W, H, n_blocks=nb, combine_layer=cl)
+    rays = orc.gen_rays(tgt[None], W, H, 32.0, 0.8, 1.8)[0].reshape(-1, 8)
+    return net, sc, rays
+
+
+def draws_for(n, kc, kf, kfd, seed):
+    rs = np.random.RandomState(seed)
+    return dict(u_coarse=rs.rand(n, kc).astype(np.float32), u_fine=rs.rand(n, max(kf - kfd, 0)).astype(np.float32),
+                u_fine2=rs.rand(n, max(kf - kfd, 0)).astype(np.float32), g_depth=rs.randn(n, kfd).astype(np.float32))
+
+
+def check_render(net, sc, rays, kc, kf, kfd, lindisp=False, white=True, max_flips=2):
+    n = rays.shape[0]
+    dr = draws_for(n, kc, kf, kfd, 7 * kc + kf)
+    ren = NeRFRenderer(n_coarse=kc, n_fine=kf, n_fine_depth=kfd, white_bkgd=white, lindisp=lindisp).eval()
+    ren.draws = dr
+    with torch.no_grad():
+        out = ren(net, dt(rays)[None], want_weights=True)
+    ref = orc.render(sc, rays, kc, kf, kfd, dr["u_coarse"], dr["u_fine"], dr["u_fine2"], dr["g_depth"],
+                     white_bkgd=white, lindisp=lindisp)
+    assert maxabs(out["coarse"]["rgb"][0], ref["coarse"]["rgb"]) < TOL
+    assert maxabs(out["coarse"]["depth"][0], ref["coarse"]["depth"]) < TOL
+    assert maxabs(out["coarse"]["weights"][0], ref["coarse"]["weights"]) < TOL
+    if kf > 0:
+        diff = (out["fine"]["rgb"][0].cpu() - ref["fine"]["rgb"]).abs().max(dim=1)[0]
+        assert int((diff > TOL).sum()) <= max_flips, diff.max()
+        assert out["fine"]["weights"].shape == (1, n, kc + kf)
+    else:
+        assert "fine" not in out
+
+
+def test_lindisp_and_fine_count_edges():
+    net, sc, rays = small_scene()
+    sub = rays[torch.arange(0, rays.shape[0], 11)[:90]]
+    check_render(net, sc, sub, 16, 8, 4, lindisp=True)        # samples linear in disparity (nerf.py:120-121,152-153)
+    check_render(net, sc, sub, 16, 8, 0)                      # importance samples only
+    check_render(net, sc, sub, 16, 8, 8)                      # depth samples only (n_fine == n_fine_depth)
+    check_render(net, sc, sub, 24, 0, 0, white=False)         # coarse only, black background
+    check_render(net, sc, sub[:1], 16, 8, 4)                  # a single ray
+
+
+def test_c4_sample_counts():
+    """BASELINE config 4 sampling (128 coarse + 64 fine, 32 depth): K = 192 > 2 wavefront chunks in
+    the composite, LDS-resident sort of 192 depths."""
+    net, sc, rays = small_scene(ns=3)
+    sub = rays[torch.arange(3, rays.shape[0], 29)[:40]]
+    check_render(net, sc, sub, 128, 64, 32)
+
+
+def test_single_view_three_block_model():
+    """conf/default.conf of the reference: n_blocks = 3, no combine_layer (single source view)."""
+    c = pconf.default_mv()
+    for k in ("mlp_coarse", "mlp_fine"):
+        c.d["model"][k] = {"type": "resnet", "n_blocks": 3, "d_hidden": 512, "d_out": 4}
+    net, sc, rays = small_scene(ns=1, conf=c, seed=60)
+    assert net.mlp_coarse.combine_layer == 1000 and len(net.mlp_coarse.lin_z) == 3
+    check_render(net, sc, rays[torch.arange(0, rays.shape[0], 13)[:70]], 16, 8, 4)
+
+
+def test_per_view_intrinsics_query():
+    net, sc, _ = small_scene(ns=3, per_view_intrinsics=True, seed=70)
+    rs = np.random.RandomState(3)
+    xyz = rs.uniform(-0.5, 0.5, size=(130, 3)).astype(np.float32)
+    vd = rs.standard_normal((130, 3)).astype(np.float32)
+    with torch.no_grad():
+        out = net(dt(xyz)[None], coarse=True, viewdirs=dt(vd)[None])[0]
+    assert maxabs(out, orc.query(sc, xyz, vd, coarse=True)) < TOL
+
+
+def test_super_batch_two_scenes():
+    """SB = 2: reference semantics are scene-major (models.py:102-112, nerf.py:197-201)."""
+    ns, H, W = 2, 32, 32
+    net = make_model(pconf.default_mv()["model"]).eval()
+    load_mlp(net.mlp_coarse, 81, 512, 4)
+    load_mlp(net.mlp_fine, 82, 512, 4)
+    net = net.to(DEV)
+    lat = np.concatenate([synth.latent(83 + i, ns, 512, H // 2, W // 2) for i in range(2)])
+    poses = np.stack([synth.scene_cameras(ns, radius=1.3 + 0.2 * i)[0] for i in range(2)])   # (SB, NS, 4, 4)
+    focal = torch.tensor([[30.0, 30.0], [34.0, 33.0]])                                         # per scene
+    net.encode(torch.zeros(2, ns, 3, H, W), torch.from_numpy(poses), focal, latent=torch.from_numpy(lat))
+    rays = torch.stack([orc.gen_rays(synth.pose_spherical(100 + 30 * i, -20, 1.3)[None], W, H, 31.0, 0.8, 1.8)[0]
+                       .reshape(-1, 8)[::17][:50] for i in range(2)])                          # (SB, 50, 8)
+    dr = draws_for(100, 16, 8, 4, 5)
+    ren = NeRFRenderer(n_coarse=16, n_fine=8, n_fine_depth=4, white_bkgd=True).eval()
+    ren.draws = dr
+    with torch.no_grad():
+        out = ren(net, rays.to(DEV))
+    assert out["fine"]["rgb"].shape == (2, 50, 3)
+    for i in range(2):
+        sc = orc.Scene(synth.mlp_state(81), synth.mlp_state(82), lat[i * ns:(i + 1) * ns], poses[i], focal[i:i + 1],
+                       None, W, H)
+        d_i = {k: v.reshape(2, 50, -1)[i] for k, v in dr.items()}
+        ref = orc.render(sc, rays[i], 16, 8, 4, d_i["u_coarse"], d_i["u_fine"], d_i["u_fine2"], d_i["g_depth"])
+        assert maxabs(out["coarse"]["rgb"][i], ref["coarse"]["rgb"]) < TOL
+        diff = (out["fine"]["rgb"][i].cpu() - ref["fine"]["rgb"]).abs().max(dim=1)[0]
+        assert int((diff > TOL).sum()) <= 1
+    with torch.no_grad():
+        q = net(torch.zeros(2, 5, 3, device=DEV), viewdirs=torch.ones(2, 5, 3, device=DEV))
+    assert q.shape == (2, 5, 4)
+
+
+def test_empty_inputs_through_the_abi(golden):
+    g = golden("nerf_c1")
+    net = nerf_net(g, 1)
+    with torch.no_grad():
+        q = net(torch.zeros(1, 0, 3, device=DEV), viewdirs=torch.zeros(1, 0, 3, device=DEV))
+    assert q.shape == (1, 0, 4)
+    ren = NeRFRenderer(n_coarse=8, n_fine=0).eval()
+    with torch.no_grad():
+        out = ren(net, torch.zeros(1, 0, 8, device=DEV))
+    assert out["coarse"]["rgb"].shape == (1, 0, 3)
+    # call-order errors are reported, not crashed on
+    fresh = make_model(pconf.default_mv()["model"]).eval().to(DEV)
+    fresh.num_objs = 1
+    with pytest.raises(plib.PnyError, match="no latent"):
+        fresh(torch.zeros(1, 4, 3, device=DEV), viewdirs=torch.zeros(1, 4, 3, device=DEV))
+
+
+def test_render_sharded_nccl_single_rank(golden, tmp_path):
+    """The multi-GPU path (ray shard + RCCL all-gather of rendered tiles) on a world of one."""
+    import torch.distributed as dist
+    from pixel_nerf_yolo_amd import dist as pdist
+    g = golden("nerf_c1")
+    net = nerf_net(g, 1)
+    ren = NeRFRenderer(n_coarse=32, n_fine=0, white_bkgd=True).eval()
+    par = ren.bind_parallel(net, None, simple_output=True)
+    rays = dt(g["rays"])
+    dist.init_process_group("nccl", init_method="file://%s" % (tmp_path / "rdzv"), rank=0, world_size=1,
+                            device_id=torch.device(DEV))
+    try:
+        def render_fn(r):
+            ren.draws = dict(u_coarse=g["u_coarse"][: r.shape[0]])
+            with torch.no_grad():
+                rgb, depth = par(r[None])
+            return rgb[0], depth[0]
+        rgb, depth = pdist.render_sharded(render_fn, rays)
+    finally:
+        dist.destroy_process_group()
+    assert rgb.shape == (80, 3) and maxabs(rgb, g["coarse_rgb"]) < TOL and maxabs(depth, g["coarse_depth"]) < TOL
