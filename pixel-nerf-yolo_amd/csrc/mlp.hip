@@ -342,10 +342,24 @@ __device__ __forceinline__ void res_block(f32x16 (&h)[C::NT][C::MT], WRing<C::WD
         ST_BEGIN();
         bias_load<NT>(bias, w.b_fc1[blk], wave, lane);
         __builtin_amdgcn_sched_barrier(0);
+#ifdef PNY_STAMP
+        const unsigned long long f0 = stamp_now();
+        __syncthreads();
+        const unsigned long long f1 = stamp_now();
+        store_relu<NT, MT>(net, act, wave, lane);
+        if (slab) slab_load<NT, MT>(net, slab);
+        const unsigned long long f2 = stamp_now();
+        __syncthreads();
+        const unsigned long long f3 = stamp_now();
+        st.acc[ST_SYNC1] += f1 - f0;
+        st.acc[ST_WRITE] += f2 - f1;
+        st.acc[ST_SYNC2] += f3 - f2;
+#else
         __syncthreads();
         store_relu<NT, MT>(net, act, wave, lane);
         if (slab) slab_load<NT, MT>(net, slab);
         __syncthreads();
+#endif
         bias_apply<NT, MT, true>(h, bias);
         ST_END(ST_STORE);
     }
