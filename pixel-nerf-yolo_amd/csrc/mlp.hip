@@ -143,14 +143,16 @@ struct WRing {
 template <int D, int NT>
 __device__ __forceinline__ void ring_fill(WRing<D, NT>& r, const WSeg& s) {
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
+    for (int d = 0; d + 1 < D; ++d) {  // slot D-1 is loaded by the segment's first step (gemm_run)
         const int j = d < s.jn ? d : s.jn - 1;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) r.f[d][nt] = s.w[((size_t)nt * s.jtot + j) * 64];
     }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) r.f[D - 1][nt] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-// acc += W_slice * act over segment `cur`; leaves the ring holding the first WDEPTH fragments of
+// acc += W_slice * act over segment `cur`; leaves the ring holding the first WDEPTH-1 fragments of
 // `next`.  Ring slots are STATIC: the loop is unrolled by the depth; slot d is consumed by the MFMAs
 // of k-iteration j+d, and slot d-1 (whose MFMAs were issued in the previous step, so no register is
 // still being read) is refilled with fragment j+d-1+WDEPTH *while* slot d's MFMAs issue.  (A rotating
@@ -184,10 +186,10 @@ __device__ __forceinline__ void gemm_run(f32x16 (&acc)[C::NT][C::MT], WRing<C::W
             const int jx = in_cur ? jj : jj - jn;  // next.jn >= WDEPTH, so jx is in range
             const float4* src = in_cur ? cur.w : next.w;
             const int sj = in_cur ? cur.jtot : next.jtot;
-            if (jd > 0) {  // at jd == 0 the previous slot still holds fragment WDEPTH-1 of this segment
+            // (at jd == 0 this loads fragment WDEPTH-1 of this very segment: on entry the ring holds
+            //  fragments 0 .. WDEPTH-2 only, so there is no special case at segment boundaries)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) r.f[dp][nt] = src[((size_t)nt * sj + jx) * 64];
-            }
+            for (int nt = 0; nt < NT; ++nt) r.f[dp][nt] = src[((size_t)nt * sj + jx) * 64];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) B[(d + 1) & 1][mt] = bp[(2 * j1) * TMc + 32 * mt];
             mfma_iter<NT, MT>(acc, r.f[d], B[d & 1]);
@@ -200,12 +202,6 @@ __device__ __forceinline__ void gemm_run(f32x16 (&acc)[C::NT][C::MT], WRing<C::W
                 __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);                        // <= 3 VALU/SALU
             }
         }
-    }
-    // the last slot of the segment was consumed in the final step: refill it for `next`
-    {
-        constexpr int dl = WDEPTH - 1;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) r.f[dl][nt] = next.w[((size_t)nt * next.jtot + dl) * 64];
     }
 }
 
