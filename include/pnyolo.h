@@ -172,6 +172,23 @@ int pny_sample_fine(const float* rays_dev, const float* z_coarse_dev, const floa
 int pny_yolo_aggregate(const float* raw_dev, int64_t n, int k, int n_anchors, float* out_dev,
                        pny_stream stream);
 
+/* ---- YOLO detection tail (callers: train/trainlib/YoloTrainer.py:283-286,347) ----
+ * Boxes are rows of 6 floats [class, score, x, y, w, h] as the reference's lists hold them. */
+/* util.convert_cells_to_bboxes for one image (src/util/util.py:633-689): cells_dev (h,w,a,7) raw
+ * predictions (is_predictions=1: sigmoid xy, exp(wh)*anchor, argmax class) or (h,w,a,6) targets;
+ * anchors_host (a,2), a <= 4; boxes_dev (h*w*a, 6) in (y, x, anchor) order. */
+int pny_cells_to_bboxes(const float* cells_dev, const float* anchors_host, int h, int w, int n_anchors,
+                        int is_predictions, float* boxes_dev, pny_stream stream);
+/* util.nms (src/util/util.py:691-722), n <= 8192, including the reference's remove-while-iterating
+ * behaviour.  kept_dev (n,6): survivors in output order; meta_dev[0] = survivors, meta_dev[1] = boxes
+ * above `threshold`; highest_conf_dev[0] = max score of all inputs (-inf when n == 0). */
+int pny_nms(const float* boxes_dev, int n, double iou_threshold, double threshold, float* kept_dev, int* meta_dev,
+            float* highest_conf_dev, pny_stream stream);
+/* util.calculate_tp_fp_fn (src/util/util.py:765-802): nms on both lists, then IoU matching.
+ * out_dev: int[3] = tp, fp, fn. */
+int pny_tp_fp_fn(const float* target_boxes_dev, int nt, const float* pred_boxes_dev, int np, double nms_iou,
+                 double nms_threshold, double match_iou, int* out_dev, pny_stream stream);
+
 /* Introspection for bench.py: name and algorithmic FLOPs (2/MAC, MLP GEMMs only) of the last
  * pny_render / pny_query on this scene, and the HIP-event time of its MLP kernel launches. */
 int pny_scene_last_mlp_stats(pny_scene* s, double* flops, double* kernel_ms, int* launches);

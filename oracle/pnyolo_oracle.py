@@ -358,3 +358,84 @@ def spatial_encoder(sd, images, prefix="encoder.model."):
     size = levels[0].shape[-2:]
     ups = [F.interpolate(l, size, mode="bilinear", align_corners=True) for l in levels]
     return torch.cat(ups, dim=1), levels
+
+
+# ----------------------------------------------------------------------------- YOLO detection tail
+def iou_xywh(a, b):
+    """src/util/util.py:576-611 (is_pred=True) on [x, y, w, h] rows, fp32 op for op (numpy float32
+    scalars: the same IEEE single-precision +,-,*,/ torch performs on its 1-element tensors)."""
+    import numpy as np
+    f = np.float32
+    a = [f(v) for v in a]
+    b = [f(v) for v in b]
+    two = f(2.0)
+    ax1, ay1, ax2, ay2 = a[0] - a[2] / two, a[1] - a[3] / two, a[0] + a[2] / two, a[1] + a[3] / two
+    bx1, by1, bx2, by2 = b[0] - b[2] / two, b[1] - b[3] / two, b[0] + b[2] / two, b[1] + b[3] / two
+    zero = f(0.0)
+    inter = max(min(ax2, bx2) - max(ax1, bx1), zero) * max(min(ay2, by2) - max(ay1, by1), zero)
+    union = abs((ax2 - ax1) * (ay2 - ay1)) + abs((bx2 - bx1) * (by2 - by1)) - inter
+    return inter / (union + f(1e-6))
+
+
+def cells_to_bboxes(cells, anchors, h, w, is_predictions=True):
+    """src/util/util.py:633-689 for one image: cells (h,w,A,7|6) -> (h*w*A, 6) [class, score, x, y, w, h]."""
+    c = T(cells)
+    A = c.shape[2]
+    box = c[..., 1:5].clone()
+    if is_predictions:
+        box[..., 0:2] = torch.sigmoid(box[..., 0:2])
+        box[..., 2:] = torch.exp(box[..., 2:]) * T(anchors).reshape(1, 1, A, 2)
+        cls = torch.argmax(c[..., 5:], dim=-1).unsqueeze(-1).to(f32)
+    else:
+        cls = c[..., 5:6]
+    cx = torch.arange(w, dtype=f32).reshape(1, w, 1, 1).expand(h, w, A, 1)
+    cy = torch.arange(h, dtype=f32).reshape(h, 1, 1, 1).expand(h, w, A, 1)
+    x = (1 / w) * (box[..., 0:1] + cx)
+    y = (1 / h) * (box[..., 1:2] + cy)
+    wh = 1 / torch.tensor([w, h], dtype=f32) * box[..., 2:4]
+    return torch.cat((cls, c[..., 0:1], x, y, wh), dim=-1).reshape(h * w * A, 6)
+
+
+def nms(boxes, iou_threshold, threshold):
+    """src/util/util.py:691-722.  boxes (n,6) fp32.  Confidence / size filters compare as Python
+    floats; the suppression loop removes from the list it iterates, so the element following a
+    removed one is skipped for that round.  Returns (kept rows, highest confidence, above-threshold count)."""
+    rows = [[float(v) for v in r] for r in T(boxes).reshape(-1, 6).tolist()]
+    highest = max(r[1] for r in rows)
+    cand = [r for r in rows if r[1] > threshold]
+    above = len(cand)
+    cand = [r for r in cand if 10e-4 < r[4] < 10e4 and 10e-4 < r[5] < 10e4]
+    order = sorted(range(len(cand)), key=lambda i: -cand[i][1])  # stable, descending
+    lst = [cand[i] for i in order]
+    thr32 = float(T(iou_threshold))
+    kept = []
+    while lst:
+        first = lst.pop(0)
+        kept.append(first)
+        i = 0
+        while i < len(lst):
+            if float(iou_xywh(first[2:], lst[i][2:])) > thr32:
+                del lst[i]   # the iterator of the reference now points past the element that moved here
+            i += 1
+    return kept, highest, above
+
+
+def tp_fp_fn(targets, preds, nms_iou, nms_t, match_iou):
+    """src/util/util.py:765-802."""
+    t, _, _ = nms(targets, nms_iou, nms_t)
+    p, _, _ = nms(preds, nms_iou, nms_t)
+    if len(t) == 0:
+        return 0, len(p), 0
+    if len(p) == 0:
+        return 0, 0, len(t)
+    m32 = float(T(match_iou))
+    tp = fp = fn = 0
+    for pb in p:
+        if max(float(iou_xywh(pb[2:], tb[2:])) for tb in t) > m32:
+            tp += 1
+        else:
+            fp += 1
+    for tb in t:
+        if max(float(iou_xywh(tb[2:], pb[2:])) for pb in p) < m32:
+            fn += 1
+    return tp, fp, fn

@@ -73,6 +73,12 @@ SIGNATURES = {
                                   C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                   C.c_void_p, C.c_void_p]),
     "pny_yolo_aggregate": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "pny_cells_to_bboxes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                      C.c_void_p]),
+    "pny_nms": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
+                          C.c_void_p]),
+    "pny_tp_fp_fn": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double,
+                               C.c_void_p, C.c_void_p]),
     "pny_scene_last_mlp_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                            C.POINTER(C.c_int)]),
     "pny_scene_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),

@@ -1,5 +1,5 @@
 """
-Ray generation with the reference's signatures (src/util/util.py:240-278 ``gen_rays``,
+Ray generation and the YOLO detection tail with the reference's signatures (src/util/util.py:240-278 ``gen_rays``,
 :808-876 ``gen_rays_yolo``), executed by libpnyolo's gen_rays kernel.  Output lives on the
 device of ``poses`` (which must be a CUDA device: there is no CPU path).
 """
@@ -56,3 +56,70 @@ def gen_rays_yolo(poses, width, height, focal, c, z_near, z_far, device=None):
     check(_lib.load().pny_gen_rays(ptr(p), B, int(width), int(height), _pair(focal, "focal"), _pair(c, "c"),
                                    float(z_near), float(z_far), 1, ptr(out), stream_of(dev)))
     return out
+
+
+# ------------------------------------------------------------------ YOLO detection tail
+def _boxes_to_dev(bboxes, dev):
+    t = torch.as_tensor(bboxes, dtype=torch.float32).reshape(-1, 6)
+    return t.to(dev).contiguous()
+
+
+def convert_cells_to_bboxes(predictions, anchors, h, w, is_predictions=True, as_tensor=False):
+    """reference src/util/util.py:633-689.  predictions (B, h, w, A, 7 | 6) on a cuda device.
+    Returns the reference's nested list (B x (A*h*w) x 6: [class, score, x, y, w, h]) or, with
+    as_tensor=True, a (B, A*h*w, 6) device tensor (no host round trip)."""
+    dev = predictions.device
+    if dev.type != "cuda":
+        raise RuntimeError("convert_cells_to_bboxes (libpnyolo) needs the cell grid on a cuda device")
+    L = _lib.load()
+    p = predictions.detach().to(torch.float32).contiguous()
+    B, A = p.shape[0], p.shape[3]
+    assert p.shape[1] == h and p.shape[2] == w and p.shape[4] == (7 if is_predictions else 6)
+    anc = torch.as_tensor(anchors, dtype=torch.float32).detach().cpu().reshape(-1, 2).contiguous()
+    assert anc.shape[0] == A
+    out = torch.empty(B, h * w * A, 6, device=dev, dtype=torch.float32)
+    for b in range(B):
+        check(L.pny_cells_to_bboxes(ptr(p[b]), ptr(anc), h, w, A, int(bool(is_predictions)), ptr(out[b]),
+                                    stream_of(dev)))
+    return out if as_tensor else out.cpu().tolist()
+
+
+def nms(bboxes, iou_threshold, threshold, device=None, as_tensor=False):
+    """reference src/util/util.py:691-722 -> (kept boxes, highest confidence, boxes above threshold).
+    bboxes: list of [class, score, x, y, w, h] or an (n, 6) tensor."""
+    dev = torch.device(device) if device is not None else (bboxes.device if torch.is_tensor(bboxes) else torch.device("cuda"))
+    b = _boxes_to_dev(bboxes, dev)
+    n = b.shape[0]
+    if n == 0:
+        raise ValueError("max() arg is an empty sequence")  # what the reference raises on an empty list
+    L = _lib.load()
+    kept = torch.empty(n, 6, device=b.device, dtype=torch.float32)
+    meta = torch.zeros(2, device=b.device, dtype=torch.int32)
+    hc = torch.empty(1, device=b.device, dtype=torch.float32)
+    check(L.pny_nms(ptr(b), n, float(iou_threshold), float(threshold), ptr(kept), C.c_void_p(meta.data_ptr()), ptr(hc),
+                    stream_of(b.device)))
+    m = meta.cpu()
+    kept = kept[: int(m[0])]
+    return (kept if as_tensor else kept.cpu().tolist()), float(hc.item()), int(m[1])
+
+
+def calculate_tp_fp_fn(target_bboxes, prediction_bboxes, nms_iou, nms_t, match_iou, print_hc=False, device=None):
+    """reference src/util/util.py:765-802 -> (tp, fp, fn)."""
+    dev = torch.device(device) if device is not None else (
+        prediction_bboxes.device if torch.is_tensor(prediction_bboxes) else torch.device("cuda"))
+    t, p = _boxes_to_dev(target_bboxes, dev), _boxes_to_dev(prediction_bboxes, dev)
+    if t.shape[0] == 0 or p.shape[0] == 0:
+        raise ValueError("max() arg is an empty sequence")  # nms() of the reference on an empty list
+    out = torch.zeros(3, device=t.device, dtype=torch.int32)
+    check(_lib.load().pny_tp_fp_fn(ptr(t), t.shape[0], ptr(p), p.shape[0], float(nms_iou), float(nms_t),
+                                   float(match_iou), C.c_void_p(out.data_ptr()), stream_of(t.device)))
+    tp, fp, fn = (int(v) for v in out.cpu())
+    return tp, fp, fn
+
+
+def calculate_precision_recall_f1(tp, fp, fn):
+    """reference src/util/util.py:798-803 (host arithmetic on three integers)."""
+    precision = tp / (tp + fp) if tp + fp > 0 else 0
+    recall = tp / (tp + fn) if tp + fn > 0 else 0
+    f1 = 2 * (precision * recall) / (precision + recall) if precision + recall > 0 else 0
+    return precision, recall, f1

@@ -503,3 +503,34 @@ def test_render_sharded_nccl_single_rank(golden, tmp_path):
     finally:
         dist.destroy_process_group()
     assert rgb.shape == (80, 3) and maxabs(rgb, g["coarse_rgb"]) < TOL and maxabs(depth, g["coarse_depth"]) < TOL
+
+
+# --------------------------------------------------------------------------- YOLO detection tail
+def test_yolo_detection_tail_golden(golden):
+    """cells -> boxes, nms (with the reference's remove-while-iterating semantics), tp/fp/fn: integer and
+    index results bit-exact against the reference's own outputs (tests/golden/yolo_tail.npz)."""
+    from pixel_nerf_yolo_amd import util as putil
+    g = golden("yolo_tail")
+    h, w, A = (int(v) for v in g["hw"])
+    anchors = torch.from_numpy(g["anchors"])
+    for c in range(3):
+        pb = putil.convert_cells_to_bboxes(dt(g["c%d_pred" % c]), anchors, h, w, True, as_tensor=True)[0]
+        tb = putil.convert_cells_to_bboxes(dt(g["c%d_tgt" % c]), anchors, h, w, False, as_tensor=True)[0]
+        assert maxabs(pb, g["c%d_p_boxes" % c]) < 2e-6     # sigmoid/exp: 1-ulp class differences allowed
+        assert maxabs(tb, g["c%d_t_boxes" % c]) == 0.0
+        lst = putil.convert_cells_to_bboxes(dt(g["c%d_tgt" % c]), anchors, h, w, False)   # reference's list form
+        assert isinstance(lst, list) and len(lst) == 1 and len(lst[0]) == h * w * A and len(lst[0][0]) == 6
+        # downstream stages on the reference's own boxes: exact
+        p_ref, t_ref = dt(g["c%d_p_boxes" % c]), dt(g["c%d_t_boxes" % c])
+        for k in range(2):
+            iou_t, conf_t, hc, above = (float(v) for v in g["c%d_nms%d_meta" % (c, k)])
+            kept, hi, ab = putil.nms(p_ref, iou_t, conf_t, as_tensor=True)
+            ref = g["c%d_nms%d_kept" % (c, k)].astype(np.float32)
+            assert kept.shape[0] == ref.shape[0] and ab == int(above) and hi == np.float32(hc)
+            assert np.array_equal(kept.cpu().numpy(), ref)
+            assert putil.calculate_tp_fp_fn(t_ref, p_ref, iou_t, conf_t, 0.2) == tuple(int(v) for v in g["c%d_tpfpfn%d" % (c, k)])
+        kept_l, _, _ = putil.nms(g["c%d_p_boxes" % c].tolist(), 0.75, 0.45, device=DEV)   # list in, list out
+        assert len(kept_l) == g["c%d_nms0_kept" % c].shape[0]
+    with pytest.raises(ValueError):
+        putil.nms([], 0.5, 0.5, device=DEV)
+    assert putil.calculate_precision_recall_f1(36, 5, 0) == (36 / 41, 1.0, 2 * (36 / 41) / (36 / 41 + 1.0))

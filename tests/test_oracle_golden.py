@@ -136,3 +136,22 @@ def test_encoder(golden):
     samp = orc.index_latent(t(g["latent"]), t(g["uv"]), int(g["W"]), int(g["H"]))
     scale = float(np.abs(g["index_out"]).max())  # random-weight trunk: activations reach O(100)
     assert maxabs(samp.permute(0, 2, 1), g["index_out"]) < 1e-6 * scale
+
+
+def test_yolo_detection_tail(golden):
+    """convert_cells_to_bboxes / nms / calculate_tp_fp_fn of the reference (util.py:633-802)."""
+    g = golden("yolo_tail")
+    h, w, A = (int(v) for v in g["hw"])
+    for c in range(3):
+        pb = orc.cells_to_bboxes(g["c%d_pred" % c][0], g["anchors"], h, w, True)
+        tb = orc.cells_to_bboxes(g["c%d_tgt" % c][0], g["anchors"], h, w, False)
+        assert maxabs(pb, g["c%d_p_boxes" % c]) == 0.0 and maxabs(tb, g["c%d_t_boxes" % c]) == 0.0
+        for k in range(2):
+            iou_t, conf_t, hc, above = g["c%d_nms%d_meta" % (c, k)]
+            kept, hi, ab = orc.nms(t(g["c%d_p_boxes" % c]), iou_t, conf_t)
+            ref = g["c%d_nms%d_kept" % (c, k)]
+            assert len(kept) == ref.shape[0] and ab == int(above) and abs(hi - hc) < 1e-12
+            if len(kept):
+                assert np.array_equal(np.array(kept, dtype=np.float32), ref.astype(np.float32))
+            assert orc.tp_fp_fn(t(g["c%d_t_boxes" % c]), t(g["c%d_p_boxes" % c]), iou_t, conf_t, 0.2) == \
+                tuple(int(v) for v in g["c%d_tpfpfn%d" % (c, k)])

@@ -451,6 +451,50 @@ def fixture_rays(name):
     print("wrote", name, r1.shape, r2.shape, r3.shape)
 
 
+def fixture_yolo_tail(name, seed=9):
+    """Detection tail of the YOLO eval path (reference util.py:633-689 convert_cells_to_bboxes,
+    :691-722 nms -- including its remove-while-iterating behaviour --, :765-802 calculate_tp_fp_fn,
+    :575-630 iou) on synthetic cell grids at the real data geometry (16 x 30 cells, 3 anchors)."""
+    import util
+
+    rs = np.random.RandomState(seed)
+    h, w, A = 16, 30, 3
+    anchors = torch.tensor([[0.28, 0.22], [0.38, 0.48], [0.9, 0.78]]) * torch.tensor([float(w), float(h)])
+    cases = {}
+    for ci, (n_obj, conf_lo) in enumerate([(6, 0.2), (25, 0.05), (0, 0.0)]):
+        pred = np.zeros((1, h, w, A, 7), dtype=np.float32)
+        pred[..., 0] = rs.uniform(0.0, conf_lo, size=(1, h, w, A))           # background confidences
+        pred[..., 1:5] = rs.standard_normal((1, h, w, A, 4)) * 0.5
+        pred[..., 3:5] -= 1.5                                                  # exp(.)*anchor stays moderate
+        pred[..., 5:7] = rs.standard_normal((1, h, w, A, 2))
+        tgt = np.zeros((1, h, w, A, 6), dtype=np.float32)
+        for _ in range(n_obj):
+            y, x, a = rs.randint(h), rs.randint(w), rs.randint(A)
+            tgt[0, y, x, a] = [1.0, rs.uniform(0.2, 0.8), rs.uniform(0.2, 0.8), rs.uniform(1.0, 4.0), rs.uniform(1.0, 4.0), rs.randint(2)]
+            # a cluster of confident, heavily overlapping predictions around the object (exercises NMS)
+            for dy, dx in ((0, 0), (0, 1), (1, 0), (0, -1)):
+                yy, xx = min(max(y + dy, 0), h - 1), min(max(x + dx, 0), w - 1)
+                for aa in range(A):
+                    if rs.rand() < 0.7:
+                        pred[0, yy, xx, aa, 0] = rs.uniform(0.5, 1.0)
+                        pred[0, yy, xx, aa, 3:5] = np.log(tgt[0, y, x, a, 3:5] / anchors[aa].numpy()) + rs.standard_normal(2) * 0.1
+        p_boxes = util.convert_cells_to_bboxes(torch.from_numpy(pred), anchors, h, w, is_predictions=True)[0]
+        t_boxes = util.convert_cells_to_bboxes(torch.from_numpy(tgt), anchors, h, w, is_predictions=False)[0]
+        d = {"pred": pred, "tgt": tgt, "p_boxes": np.array(p_boxes, dtype=np.float64), "t_boxes": np.array(t_boxes, dtype=np.float64)}
+        for thr_i, (iou_t, conf_t) in enumerate([(0.75, 0.45), (0.3, 0.1)]):
+            kept, hc, above = util.nms([list(b) for b in p_boxes], iou_t, conf_t)
+            d["nms%d_kept" % thr_i] = np.array(kept, dtype=np.float64).reshape(-1, 6)
+            d["nms%d_meta" % thr_i] = np.array([iou_t, conf_t, hc, above], dtype=np.float64)
+            tp, fp, fn = util.calculate_tp_fp_fn([list(b) for b in t_boxes], [list(b) for b in p_boxes], iou_t, conf_t, 0.2)
+            d["tpfpfn%d" % thr_i] = np.array([tp, fp, fn], dtype=np.int64)
+        for k, v in d.items():
+            cases["c%d_%s" % (ci, k)] = v
+    cases["anchors"] = anchors.numpy()
+    cases["hw"] = np.array([h, w, A])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **cases)
+    print("wrote", name, {k: v.shape for k, v in cases.items() if "kept" in k or "tpfpfn" in k})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_shims()
@@ -461,6 +505,7 @@ def main():
     fixture_nerf("nerf_c2", H=128, NS=3, Kc=64, Kf=32, Kfd=16, n_rays=100, seed=7, ebs=3000)
     fixture_yolo("yolo_c3", seed=3)
     fixture_encoder("encoder", seed=4)
+    fixture_yolo_tail("yolo_tail")
 
 
 if __name__ == "__main__":

@@ -4,5 +4,5 @@
 set -e
 cd "$(dirname "$0")/../pixel-nerf-yolo_amd/csrc"
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -DPNY_STAMP"
-/opt/rocm/bin/hipcc $FLAGS -shared api.hip mlp.hip render_kernels.hip encoder.hip -o ../libpnyolo_stamp.so
+/opt/rocm/bin/hipcc $FLAGS -shared api.hip mlp.hip render_kernels.hip encoder.hip detect.hip -o ../libpnyolo_stamp.so
 echo built ../libpnyolo_stamp.so
