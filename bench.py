@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--cpu-rays", type=int, default=256, help="ray subset for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-rays", type=int, default=1536, help="ray subset for the CPU baseline (0 = skip)")
     ap.add_argument("--describe", action="store_true", help="print the workload description and exit (no GPU)")
     args = ap.parse_args()
     if args.describe:
