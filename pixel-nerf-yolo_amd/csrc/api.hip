@@ -82,16 +82,19 @@ struct pny_scene {
 };
 
 // ---------------------------------------------------------------------------------- packing
-// A-operand order of v_mfma_f32_32x32x2_f32 for H^T = W X^T (see mlp.hip): for n-tile nt (32
-// output features), k-iteration j (8 inputs), lane l, component r:
-//     Wp[((nt*J + j)*64 + l)*4 + r] = W[32 nt + (l & 31)][8 j + 4 (l >> 5) + r]   (0 beyond K)
+// A-operand order of v_mfma_f32_32x32x2_f32 for H^T = W X^T (see mlp.hip): for k-iteration j (8
+// inputs), n-tile nt (32 output features), lane l, component r:
+//     Wp[((j*NT + nt)*64 + l)*4 + r] = W[32 nt + (l & 31)][8 j + 4 (l >> 5) + r]   (0 beyond K)
+// k-iteration-major: the 16 KiB that ALL waves of a workgroup need for iteration j are contiguous,
+// so the 16 per-wave streams of a CU walk the same pages together (measured +1 % over n-tile-major,
+// where each stream strides through its own 64 KiB region).
 static void pack_layer(const float* W, int n_out, int k_in, int k_pad, std::vector<float>& dst) {
     const int J = k_pad / 8, NT = n_out / 32;
     const size_t base = dst.size();
     dst.resize(base + (size_t)NT * J * 64 * 4);
     float* o = dst.data() + base;
-    for (int nt = 0; nt < NT; ++nt)
-        for (int j = 0; j < J; ++j)
+    for (int j = 0; j < J; ++j)
+        for (int nt = 0; nt < NT; ++nt)
             for (int l = 0; l < 64; ++l)
                 for (int r = 0; r < 4; ++r) {
                     const int n = 32 * nt + (l & 31), k = 8 * j + 4 * (l >> 5) + r;
@@ -513,6 +516,10 @@ static int run_mlp(pny_scene* s, int mode, const float* xyz, const float* dirs, 
     if (tiles > 0x7fffffffll) return fail(PNY_ERR_ARG, "too many points for one launch");
     a.n_tiles = (int)tiles;
     int grid = mlp_max_grid();
+    if (const char* e = getenv("PNYOLO_GRID")) {  // diagnostic: fewer resident workgroups
+        const int g = atoi(e);
+        if (g > 0 && g < grid) grid = g;
+    }
     if (tiles < grid) grid = (int)tiles;
     int rc;
     if ((rc = s->scratch.reserve(mlp_scratch_floats() * sizeof(float)))) return rc;

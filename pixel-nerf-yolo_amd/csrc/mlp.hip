@@ -121,19 +121,22 @@ __device__ __forceinline__ void mfma_iter(f32x16 (&acc)[NT][MT], const float4 (&
 // fragments in flight and runs ACROSS layer boundaries: while a GEMM drains, the ring already fills
 // with the head of the next layer's slice (WSeg next), so neither the epilogue/barrier phase nor the
 // head of a GEMM waits on memory.
-struct WSeg {  // this wave's slice of one packed layer: fragment j of its n-tile t at w[(t*jtot + j)*64]
+// Packed layout (api.hip pack_layer): k-iteration-major, [j][n-tile 0..15][lane] float4.
+struct WSeg {  // this wave's slice of one packed layer: fragment j of its n-tile t at w[(j*16 + t)*64]
     const float4* w;
-    int jtot;
+    int jtot;  // (unused by the k-iteration-major layout; kept for segment bookkeeping)
     int jn;
 };
 template <int NT>
 __device__ __forceinline__ WSeg wseg(const float* packed, int jtot, int j0, int jn, int wave, int lane) {
     WSeg s;
-    s.w = reinterpret_cast<const float4*>(packed) + ((size_t)(NT * wave) * jtot + j0) * 64 + lane;
+    s.w = reinterpret_cast<const float4*>(packed) + ((size_t)j0 * 16 + NT * wave) * 64 + lane;
     s.jtot = jtot;
     s.jn = jn;
     return s;
 }
+// fragment (k-iteration j, local n-tile nt) of a segment
+__device__ __forceinline__ const float4* wfrag(const WSeg& s, int nt, int j) { return s.w + ((size_t)j * 16 + nt) * 64; }
 
 template <int D, int NT>
 struct WRing {
@@ -146,7 +149,7 @@ __device__ __forceinline__ void ring_fill(WRing<D, NT>& r, const WSeg& s) {
     for (int d = 0; d + 1 < D; ++d) {  // slot D-1 is loaded by the segment's first step (gemm_run)
         const int j = d < s.jn ? d : s.jn - 1;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) r.f[d][nt] = s.w[((size_t)nt * s.jtot + j) * 64];
+        for (int nt = 0; nt < NT; ++nt) r.f[d][nt] = *wfrag(s, nt, j);
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) r.f[D - 1][nt] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -185,11 +188,10 @@ __device__ __forceinline__ void gemm_run(f32x16 (&acc)[C::NT][C::MT], WRing<C::W
             const bool in_cur = jj < jn;
             const int jx = in_cur ? jj : jj - jn;  // next.jn >= WDEPTH, so jx is in range
             const float4* src = in_cur ? cur.w : next.w;
-            const int sj = in_cur ? cur.jtot : next.jtot;
             // (at jd == 0 this loads fragment WDEPTH-1 of this very segment: on entry the ring holds
             //  fragments 0 .. WDEPTH-2 only, so there is no special case at segment boundaries)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) r.f[dp][nt] = src[((size_t)nt * sj + jx) * 64];
+            for (int nt = 0; nt < NT; ++nt) r.f[dp][nt] = src[((size_t)jx * 16 + nt) * 64];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) B[(d + 1) & 1][mt] = bp[(2 * j1) * TMc + 32 * mt];
             mfma_iter<NT, MT>(acc, r.f[d], B[d & 1]);
