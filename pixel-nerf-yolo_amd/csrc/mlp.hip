@@ -141,6 +141,10 @@ __device__ __forceinline__ const float4* wfrag(const WSeg& s, int nt, int j) { r
 template <int D, int NT>
 struct WRing {
     float4 f[D][NT];
+#ifdef PNY_EXP_FOOT  // timing-only experiment: stream cyclically through the first PNY_EXP_FOOT k-iterations
+    const float4* exp_base;  // (16 KiB each) of the packed blob instead of the real layers (wrong results)
+    int exp_ctr;
+#endif
 };
 
 template <int D, int NT>
@@ -190,8 +194,19 @@ __device__ __forceinline__ void gemm_run(f32x16 (&acc)[C::NT][C::MT], WRing<C::W
             const float4* src = in_cur ? cur.w : next.w;
             // (at jd == 0 this loads fragment WDEPTH-1 of this very segment: on entry the ring holds
             //  fragments 0 .. WDEPTH-2 only, so there is no special case at segment boundaries)
+#ifdef PNY_EXP_FOOT
+            {
+                (void)src;
+                (void)jx;
+                const int it = r.exp_ctr;
+                r.exp_ctr = (it + 1 == PNY_EXP_FOOT) ? 0 : it + 1;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) r.f[dp][nt] = r.exp_base[((size_t)it * 16 + nt) * 64];
+            }
+#else
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) r.f[dp][nt] = src[((size_t)jx * 16 + nt) * 64];
+#endif
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) B[(d + 1) & 1][mt] = bp[(2 * j1) * TMc + 32 * mt];
             mfma_iter<NT, MT>(acc, r.f[d], B[d & 1]);
@@ -577,6 +592,10 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void pny_mlp_kernel(const MlpAr
     };
     WRing<C::WDEPTH, NT> ring;
     ring_fill(ring, s_in);
+#ifdef PNY_EXP_FOOT
+    ring.exp_base = s_in.w;
+    ring.exp_ctr = 0;
+#endif
 
     for (long long tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         f32x16 h[NT][MT];
