@@ -30,11 +30,17 @@ struct ConvArgs {
     long long npix;
 };
 
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
+// SPLIT = 1: 4 waves per workgroup, one 64x64 output tile each.
+// SPLIT = 8: 8 waves per workgroup share ONE output tile, wave w takes k-iterations j = w (mod 8); the
+//            partial accumulators are reduced through LDS (8 x 16 KiB) and wave w finishes registers
+//            [8w, 8w+8) of every tile position.  Used for the deep, spatially small layers, where a
+//            tile per wave leaves 3-12 workgroups on the chip running up to 288 dependent iterations.
+template <int SPLIT>
+__global__ __launch_bounds__(SPLIT == 1 ? 256 : 512) void conv_mfma_kernel(const ConvArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m0 = lane & 31, hh = lane >> 5;
     const int tiles_n = a.cout / 64;
-    const long long tile = (long long)blockIdx.x * 4 + wave;
+    const long long tile = SPLIT == 1 ? (long long)blockIdx.x * 4 + wave : (long long)blockIdx.x;
     const long long tile_m = tile / tiles_n;
     const int tile_n = (int)(tile - tile_m * tiles_n);
     if (tile_m * 64 >= a.npix) return;
@@ -66,29 +72,90 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     const float4* w0 = reinterpret_cast<const float4*>(a.w) + (size_t)(2 * tile_n) * a.J * 64 + lane;
     const float4* w1 = w0 + (size_t)a.J * 64;
     const int ntap = a.k * a.k;
-    for (int j = 0; j < a.J; ++j) {
-        const int k0 = 8 * j + 4 * hh;
+    // One k-iteration's operands: 2 weight fragments (packed, coalesced) and 2 patch fragments
+    // (4 consecutive input channels of one tap per lane; zero outside the image / beyond K).
+    struct Frag {
+        float4 a0, a1, b[2];
+    };
+    auto fetch = [&](int j, Frag& f) {
+        const int jj = j < a.J ? j : a.J - 1;  // clamped prefetch past the end (discarded)
+        const int k0 = 8 * jj + 4 * hh;
         const int tap = k0 / a.cin_p, ci = k0 - tap * a.cin_p;
         const int ky = tap / a.k, kx = tap - ky * a.k;
-        const float4 a0 = w0[(size_t)j * 64], a1 = w1[(size_t)j * 64];
-        float4 b[2];
+        f.a0 = w0[(size_t)jj * 64];
+        f.a1 = w1[(size_t)jj * 64];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int iy = iy0[mt] + ky, ix = ix0[mt] + kx;
             const bool ok = valid[mt] && tap < ntap && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
-            b[mt] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) b[mt] = *reinterpret_cast<const float4*>(a.in + (((size_t)img[mt] * a.hin + iy) * a.win + ix) * a.cin_p + ci);
+            f.b[mt] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) f.b[mt] = *reinterpret_cast<const float4*>(a.in + (((size_t)img[mt] * a.hin + iy) * a.win + ix) * a.cin_p + ci);
         }
-#define PNY_STEP(c)                                                                           \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c, b[0].c, acc[0][0], 0, 0, 0);       \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c, b[1].c, acc[0][1], 0, 0, 0);       \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c, b[0].c, acc[1][0], 0, 0, 0);       \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c, b[1].c, acc[1][1], 0, 0, 0);
+    };
+    auto mac = [&](const Frag& f) {
+#define PNY_STEP(c)                                                                             \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0.c, f.b[0].c, acc[0][0], 0, 0, 0);     \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0.c, f.b[1].c, acc[0][1], 0, 0, 0);     \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1.c, f.b[0].c, acc[1][0], 0, 0, 0);     \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1.c, f.b[1].c, acc[1][1], 0, 0, 0);
         PNY_STEP(x)
         PNY_STEP(y)
         PNY_STEP(z)
         PNY_STEP(w)
 #undef PNY_STEP
+    };
+    // static 3-slot software pipeline (slots never copied: see mlp.hip gemm_run): operands run two
+    // k-iterations ahead of the MFMAs; these small convolutions are otherwise one L2 round trip per
+    // iteration (up to 288 dependent iterations).
+    Frag f0, f1, f2;
+    const int jb = SPLIT == 1 ? 0 : wave;  // first k-iteration of this wave, stride SPLIT
+    fetch(jb, f0);
+    fetch(jb + SPLIT, f1);
+    for (int j = jb; j < a.J; j += 3 * SPLIT) {
+        fetch(j + 2 * SPLIT, f2);
+        __builtin_amdgcn_sched_barrier(0);
+        mac(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + SPLIT < a.J) {
+            fetch(j + 3 * SPLIT, f0);
+            __builtin_amdgcn_sched_barrier(0);
+            mac(f1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (j + 2 * SPLIT < a.J) {
+            fetch(j + 4 * SPLIT, f1);
+            __builtin_amdgcn_sched_barrier(0);
+            mac(f2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (SPLIT > 1) {
+        // reduce the SPLIT partial tiles: part[wave][tile position (nt,mt)][reg][lane]
+        extern __shared__ float part[];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) part[((wave * 4 + nt * 2 + mt) * 16 + r) * 64 + lane] = acc[nt][mt][r];
+        __syncthreads();
+        // each wave finishes 8 of the 64 (position, reg) pairs: pairs p = 8*wave .. 8*wave+7
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int pr = 8 * wave + i;  // = (nt*2+mt)*16 + r
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < SPLIT; ++w) sum += part[((w * 4) * 16 + pr) * 64 + lane];
+            const int pos = pr >> 4, r = pr & 15, nt = pos >> 1, mt = pos & 1;
+            if (!valid[mt]) continue;
+            const int c = 64 * tile_n + 32 * nt + 8 * (r >> 2) + 4 * hh + (r & 3);
+            float v = sum * a.scale[c] + a.shift[c];
+            const size_t o = (size_t)pix[mt] * a.cout + c;
+            if (a.resid) v += a.resid[o];
+            if (a.relu) v = fmaxf(v, 0.f);
+            a.out[o] = v;
+        }
+        return;
     }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -338,7 +405,19 @@ static bool run_conv(const ConvLayer& L, const float* in, int n, int hin, int wi
     a.relu = relu;
     a.npix = (long long)n * a.hout * a.wout;
     const long long tiles = ((a.npix + 63) / 64) * (L.cout / 64);
-    hipLaunchKernelGGL(conv_mfma_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, a);
+    // split K inside the workgroup when there are few tiles and a long reduction
+    if (L.J >= 32 && tiles <= 512) {
+        constexpr int lds = 8 * 4 * 16 * 64 * (int)sizeof(float);  // 128 KiB
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<8>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(conv_mfma_kernel<8>, dim3((unsigned)tiles), dim3(512), lds, st, a);
+    } else {
+        hipLaunchKernelGGL(conv_mfma_kernel<1>, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, a);
+    }
     return hipGetLastError() == hipSuccess;
 }
 
