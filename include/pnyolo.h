@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PNY_ABI_VERSION 1
+#define PNY_ABI_VERSION 2
 
 typedef enum pny_status {
     PNY_OK = 0,
@@ -56,6 +56,7 @@ typedef struct pny_model_desc {
     int32_t yolo;          /* mlp_coarse.yolo: raw outputs, extrinsics used as given, z>=0 culling */
     int32_t has_fine;      /* mlp_fine.type != empty */
     int32_t device;        /* HIP device ordinal */
+    int32_t enc_use_first_pool; /* encoder.use_first_pool (encoder.py:145-146); 0 in conf/exp/sn64.conf */
 } pny_model_desc;
 
 int pny_version(void);

@@ -340,7 +340,7 @@ def _block(sd, p, x, stride):
     return torch.relu(out + idt)
 
 
-def spatial_encoder(sd, images, prefix="encoder.model."):
+def spatial_encoder(sd, images, prefix="encoder.model.", use_first_pool=True):
     """src/model/encoder.py:139-173 with num_layers=4, use_first_pool, eval-mode batch norm:
     conv1/bn1/relu -> L0; maxpool, layer1 -> L1; layer2 -> L2; layer3 -> L3; every level
     bilinearly upsampled (align_corners=True) to L0's size; channel concat (64+64+128+256).
@@ -350,7 +350,8 @@ def spatial_encoder(sd, images, prefix="encoder.model."):
     x = T(images)
     x = torch.relu(_bn(sd, "bn1", F.conv2d(x, sd["conv1.weight"], stride=2, padding=3)))
     levels = [x]
-    x = F.max_pool2d(x, 3, 2, 1)
+    if use_first_pool:  # encoder.py:145-146 (sn64.conf sets use_first_pool = False)
+        x = F.max_pool2d(x, 3, 2, 1)
     for li, n in ((1, 3), (2, 4), (3, 6)):
         for b in range(n):
             x = _block(sd, "layer%d.%d." % (li, b), x, 2 if (b == 0 and li > 1) else 1)

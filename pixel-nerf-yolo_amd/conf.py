@@ -81,3 +81,17 @@ def yolo():
     d["model"]["mlp_fine"] = {"type": "empty"}
     d["model"]["encoder"]["backbone"] = "custom"
     return Conf(d)
+
+
+def sn64():
+    """conf/exp/sn64.conf (and sn64_unseen.conf): default_mv with encoder.use_first_pool = False."""
+    d = copy.deepcopy(_DEFAULT_MV)
+    d["model"]["encoder"]["use_first_pool"] = False
+    return Conf(d)
+
+
+def dtu():
+    """conf/exp/dtu.conf: default_mv with a black background."""
+    d = copy.deepcopy(_DEFAULT_MV)
+    d["renderer"]["white_bkgd"] = False
+    return Conf(d)

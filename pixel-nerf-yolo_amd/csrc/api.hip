@@ -351,9 +351,10 @@ int pny_scene_encode(pny_scene* s, const float* images_dev, int ns, int height, 
     encoder_latent_size(height, width, &hl, &wl);
     int rc;
     if ((rc = s->latent.reserve((size_t)ns * 512 * hl * wl * sizeof(float)))) return rc;
-    if ((rc = s->enc_work.reserve(encoder_workspace_bytes(ns, height, width)))) return rc;
+    const bool pool = s->m->desc.enc_use_first_pool != 0;
+    if ((rc = s->enc_work.reserve(encoder_workspace_bytes(ns, height, width, pool)))) return rc;
     std::string err;
-    if (!encoder_forward(s->m->enc, images_dev, ns, height, width, s->enc_work.f(), s->latent.f(), (hipStream_t)stream, &err))
+    if (!encoder_forward(s->m->enc, images_dev, ns, height, width, pool, s->enc_work.f(), s->latent.f(), (hipStream_t)stream, &err))
         return fail(PNY_ERR_HIP, "pny_scene_encode: " + err);
     s->ns = ns;
     s->L = 512;

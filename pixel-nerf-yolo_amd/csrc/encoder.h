@@ -31,9 +31,9 @@ struct EncoderWeights {
 };
 
 void encoder_latent_size(int height, int width, int* hl, int* wl);
-size_t encoder_workspace_bytes(int ns, int height, int width);
+size_t encoder_workspace_bytes(int ns, int height, int width, bool use_first_pool);
 // images (ns,3,H,W) NCHW -> latent (ns, H0, W0, 512) channel-last
-bool encoder_forward(const EncoderWeights& w, const float* images, int ns, int height, int width, float* work,
-                     float* latent_nhwc, hipStream_t st, std::string* err);
+bool encoder_forward(const EncoderWeights& w, const float* images, int ns, int height, int width, bool use_first_pool,
+                     float* work, float* latent_nhwc, hipStream_t st, std::string* err);
 
 }  // namespace pny

@@ -358,12 +358,13 @@ void encoder_latent_size(int height, int width, int* hl, int* wl) {
 struct Dims {
     int h[4], w[4];
 };
-static Dims pyramid(int height, int width) {
+static Dims pyramid(int height, int width, bool use_first_pool) {
     Dims d;
     d.h[0] = conv_out(height, 7, 2, 3);
     d.w[0] = conv_out(width, 7, 2, 3);
-    d.h[1] = conv_out(d.h[0], 3, 2, 1);
-    d.w[1] = conv_out(d.w[0], 3, 2, 1);
+    // reference encoder.py:145-146: the max-pool in front of layer1 is optional (sn64.conf skips it)
+    d.h[1] = use_first_pool ? conv_out(d.h[0], 3, 2, 1) : d.h[0];
+    d.w[1] = use_first_pool ? conv_out(d.w[0], 3, 2, 1) : d.w[0];
     for (int i = 2; i < 4; ++i) {
         d.h[i] = conv_out(d.h[i - 1], 3, 2, 1);
         d.w[i] = conv_out(d.w[i - 1], 3, 2, 1);
@@ -373,8 +374,8 @@ static Dims pyramid(int height, int width) {
 
 static size_t align64(size_t x) { return (x + 63) & ~(size_t)63; }
 
-size_t encoder_workspace_bytes(int ns, int height, int width) {
-    const Dims d = pyramid(height, width);
+size_t encoder_workspace_bytes(int ns, int height, int width, bool use_first_pool) {
+    const Dims d = pyramid(height, width, use_first_pool);
     size_t fl = align64((size_t)ns * height * width * 4);          // nhwc4 image
     fl += align64((size_t)ns * d.h[0] * d.w[0] * 64);              // level 0
     const int ch[4] = {64, 64, 128, 256};
@@ -421,9 +422,9 @@ static bool run_conv(const ConvLayer& L, const float* in, int n, int hin, int wi
     return hipGetLastError() == hipSuccess;
 }
 
-bool encoder_forward(const EncoderWeights& W, const float* images, int ns, int height, int width, float* work,
-                     float* lat, hipStream_t st, std::string* err) {
-    const Dims d = pyramid(height, width);
+bool encoder_forward(const EncoderWeights& W, const float* images, int ns, int height, int width, bool use_first_pool,
+                     float* work, float* lat, hipStream_t st, std::string* err) {
+    const Dims d = pyramid(height, width, use_first_pool);
     size_t off = 0;
     auto carve = [&](size_t n) {
         float* p = work + off;
@@ -445,12 +446,14 @@ bool encoder_forward(const EncoderWeights& W, const float* images, int ns, int h
     hipLaunchKernelGGL(image_to_nhwc4_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, st, images, img4, ns,
                        height * width);
     if (!run_conv(W.conv1, img4, ns, height, width, nullptr, 1, l0, st)) return bad();
-    const long long npool = (long long)ns * d.h[1] * d.w[1] * 16;
-    hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)((npool + 255) / 256)), dim3(256), 0, st, l0, buf[1][0], ns,
-                       d.h[0], d.w[0], 64, d.h[1], d.w[1]);
+    if (use_first_pool) {
+        const long long npool = (long long)ns * d.h[1] * d.w[1] * 16;
+        hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)((npool + 255) / 256)), dim3(256), 0, st, l0, buf[1][0], ns,
+                           d.h[0], d.w[0], 64, d.h[1], d.w[1]);
+    }
 
     const float* level_out[4] = {l0, nullptr, nullptr, nullptr};
-    const float* x = buf[1][0];
+    const float* x = use_first_pool ? buf[1][0] : l0;
     int hin = d.h[1], win = d.w[1];
     for (int li = 0; li < 3; ++li) {
         const int lv = li + 1;

@@ -22,7 +22,7 @@ class ModelDesc(C.Structure):
     _fields_ = [
         ("d_latent", C.c_int32), ("d_hidden", C.c_int32), ("d_out", C.c_int32), ("n_blocks", C.c_int32),
         ("combine_layer", C.c_int32), ("num_freqs", C.c_int32), ("freq_factor", C.c_float),
-        ("yolo", C.c_int32), ("has_fine", C.c_int32), ("device", C.c_int32),
+        ("yolo", C.c_int32), ("has_fine", C.c_int32), ("device", C.c_int32), ("enc_use_first_pool", C.c_int32),
     ]
 
 
@@ -119,7 +119,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.pny_version() != 1:
+    if lib.pny_version() != 2:
         raise PnyError("libpnyolo.so ABI version mismatch")
     _lib = lib
     return lib

@@ -135,10 +135,9 @@ class SpatialEncoder(nn.Module):
             self.latent_size = 1792  # reference custom_encoder.py:22
             self.model = nn.Module()
         else:
-            if backbone != "resnet34" or num_layers != 4 or norm_type != "batch" or not use_first_pool \
-                    or feature_scale != 1.0:
+            if backbone != "resnet34" or num_layers != 4 or norm_type != "batch" or feature_scale != 1.0:
                 raise NotImplementedError("libpnyolo's encoder kernels cover backbone=resnet34, num_layers=4, batch "
-                                          "norm, use_first_pool, feature_scale=1 (the shipped multi-view configs)")
+                                          "norm, feature_scale=1 (every shipped conf/exp/*.conf)")
             self.latent_size = [0, 64, 128, 256, 512, 1024][num_layers]
             self.model = _resnet34_params()
             # `pretrained` ImageNet weights cannot be downloaded here; they arrive via load_weights
@@ -146,6 +145,7 @@ class SpatialEncoder(nn.Module):
             raise NotImplementedError("libpnyolo supports bilinear indexing with zeros padding "
                                       "(conf/default.conf:49 of the reference)")
         self.num_layers = num_layers
+        self.use_first_pool = use_first_pool
         self.index_interp, self.index_padding, self.upsample_interp = index_interp, index_padding, upsample_interp
 
     @classmethod
@@ -264,7 +264,8 @@ class PixelNeRFNet(nn.Module):
             desc = ModelDesc(d_latent=self.d_latent, d_hidden=mc.d_hidden, d_out=self.d_out, n_blocks=mc.n_blocks,
                              combine_layer=min(mc.combine_layer, 1 << 20), num_freqs=self.code.num_freqs,
                              freq_factor=float(self.code.freq_factor), yolo=int(self.yolo),
-                             has_fine=int(has_fine), device=dev.index or 0)
+                             has_fine=int(has_fine), device=dev.index or 0,
+                             enc_use_first_pool=int(getattr(self.encoder, "use_first_pool", True)))
             h = C.c_void_p()
             check(L.pny_model_create(C.byref(h), C.byref(desc)))
             self._h_model, self._h_device, self._h_has_fine, self._synced_key = h, str(dev), has_fine, None

@@ -534,3 +534,24 @@ def test_yolo_detection_tail_golden(golden):
     with pytest.raises(ValueError):
         putil.nms([], 0.5, 0.5, device=DEV)
     assert putil.calculate_precision_recall_f1(36, 5, 0) == (36 / 41, 1.0, 2 * (36 / 41) / (36 / 41 + 1.0))
+
+
+def test_encoder_sn64_config_golden(golden):
+    """conf/exp/sn64.conf: use_first_pool = False (no max-pool in front of layer1)."""
+    g = golden("encoder_nopool")
+    c = pconf.sn64()
+    net = make_model(c["model"]).eval()
+    assert net.encoder.use_first_pool is False
+    sd = synth.resnet34_state(55, prefix="encoder.model.")
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    net = net.to(DEV)
+    ns, H, W = int(g["NS"]), int(g["H"]), int(g["W"])
+    img = torch.from_numpy(synth.images(56, ns, H, W))
+    src, _ = synth.scene_cameras(ns)
+    net.encode(img[None], torch.from_numpy(src)[None], torch.tensor(40.0))
+    lat = net.latent(0)
+    assert lat.shape == g["latent"].shape
+    assert maxabs(lat, g["latent"]) < 2e-5 * float(np.abs(g["latent"]).max())
+    # dtu.conf: black background renderer
+    ren = make_renderer(pconf.dtu())
+    assert isinstance(ren, NeRFRenderer) and not ren.white_bkgd

@@ -155,3 +155,13 @@ def test_yolo_detection_tail(golden):
                 assert np.array_equal(np.array(kept, dtype=np.float32), ref.astype(np.float32))
             assert orc.tp_fp_fn(t(g["c%d_t_boxes" % c]), t(g["c%d_p_boxes" % c]), iou_t, conf_t, 0.2) == \
                 tuple(int(v) for v in g["c%d_tpfpfn%d" % (c, k)])
+
+
+def test_encoder_without_first_pool(golden):
+    """conf/exp/sn64.conf of the reference: encoder.use_first_pool = False (encoder.py:145-146)."""
+    g = golden("encoder_nopool")
+    sd = synth.resnet34_state(55, prefix="encoder.model.")
+    img = synth.images(56, int(g["NS"]), int(g["H"]), int(g["W"]))
+    lat, levels = orc.spatial_encoder(sd, img, use_first_pool=False)
+    assert lat.shape == g["latent"].shape and levels[1].shape[-2:] == levels[0].shape[-2:]
+    assert maxabs(lat, g["latent"]) < 1e-6 * float(np.abs(g["latent"]).max())

@@ -407,13 +407,14 @@ def fixture_yolo(name, seed, n_rays=40, K=128, ebs=128):
     print("wrote", name, d["raw_out"].shape, d["yolo_out"].shape)
 
 
-def fixture_encoder(name, seed, NS=2, H=64, W=48):
+def fixture_encoder(name, seed, NS=2, H=64, W=48, use_first_pool=True):
     """SpatialEncoder.forward (reference encoder.py:110-173) over the ResNet-34 skeleton with
     seeded random weights, eval-mode batch norm."""
     from model.encoder import SpatialEncoder
 
     torch.manual_seed(seed)
-    enc = SpatialEncoder(backbone="resnet34", pretrained=False, num_layers=4, index_padding="zeros").eval()
+    enc = SpatialEncoder(backbone="resnet34", pretrained=False, num_layers=4, index_padding="zeros",
+                         use_first_pool=use_first_pool).eval()
     sd = synth.resnet34_state(seed * 10 + 5, prefix="model.")
     missing = enc.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
     assert all(k.startswith(("model.layer4", "model.fc")) or "num_batches_tracked" in k for k in missing.missing_keys), missing
@@ -506,6 +507,7 @@ def main():
     fixture_yolo("yolo_c3", seed=3)
     fixture_encoder("encoder", seed=4)
     fixture_yolo_tail("yolo_tail")
+    fixture_encoder("encoder_nopool", seed=5, NS=1, H=48, W=32, use_first_pool=False)  # conf/exp/sn64.conf
 
 
 if __name__ == "__main__":
