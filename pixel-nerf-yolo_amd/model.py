@@ -10,7 +10,6 @@ the C ABI (include/pnyolo.h).  Forward only -- a call under autograd raises (bac
 "next" row of SURVEY.md 8f).
 """
 import ctypes as C
-import os
 import os.path as osp
 import warnings
 
@@ -414,31 +413,39 @@ class PixelNeRFNet(nn.Module):
         return out
 
     # ---------------------------------------------------------------- checkpoints
+    @staticmethod
+    def _ckpt_paths(args, opt_init):
+        """File layout of the reference (models.py:320-370): checkpoints/<name>/pixel_nerf_{latest,init}
+        plus a *_backup copy written before each overwrite."""
+        stem = "pixel_nerf_init" if opt_init else "pixel_nerf_latest"
+        backup = "pixel_nerf_init_backup" if opt_init else "pixel_nerf_backup"
+        root = osp.join(args.checkpoints_path, args.name)
+        return osp.join(root, stem), osp.join(root, backup)
+
     def load_weights(self, args, opt_init=False, strict=True, device=None):
-        """reference models.py:320-349: checkpoints/<name>/pixel_nerf_latest (or pixel_nerf_init)."""
+        """Same contract as reference models.py:320-349: load <checkpoints_path>/<name>/pixel_nerf_latest
+        (pixel_nerf_init with opt_init, only when resuming); warn -- do not fail -- when it is absent.
+        The file is a plain state_dict and is read with weights_only=True."""
         if opt_init and not args.resume:
-            return
-        ckpt_name = "pixel_nerf_init" if opt_init else "pixel_nerf_latest"
-        model_path = "%s/%s/%s" % (args.checkpoints_path, args.name, ckpt_name)
-        if device is None:
-            device = self.mlp_coarse.lin_in.weight.device
-        if os.path.exists(model_path):
-            print("Load", model_path)
-            self.load_state_dict(torch.load(model_path, map_location=device, weights_only=True), strict=strict)
-        elif not opt_init:
-            warnings.warn("WARNING: {} does not exist, not loaded!! Model will be re-initialized.".format(model_path))
+            return self
+        path, _ = self._ckpt_paths(args, opt_init)
+        if not osp.exists(path):
+            if not opt_init:
+                warnings.warn("WARNING: {} does not exist, not loaded!! Model will be re-initialized.".format(path))
+            return self
+        target = device if device is not None else self.mlp_coarse.lin_in.weight.device
+        print("Load", path)
+        state = torch.load(path, map_location=target, weights_only=True)
+        self.load_state_dict(state, strict=strict)
         return self
 
     def save_weights(self, args, opt_init=False):
-        """reference models.py:351-370"""
-        from shutil import copyfile
-        ckpt_name = "pixel_nerf_init" if opt_init else "pixel_nerf_latest"
-        backup_name = "pixel_nerf_init_backup" if opt_init else "pixel_nerf_backup"
-        ckpt_path = osp.join(args.checkpoints_path, args.name, ckpt_name)
-        ckpt_backup_path = osp.join(args.checkpoints_path, args.name, backup_name)
-        if osp.exists(ckpt_path):
-            copyfile(ckpt_path, ckpt_backup_path)
-        torch.save(self.state_dict(), ckpt_path)
+        """Same contract as reference models.py:351-370 (previous file kept as *_backup)."""
+        import shutil
+        path, backup = self._ckpt_paths(args, opt_init)
+        if osp.exists(path):
+            shutil.copyfile(path, backup)
+        torch.save(self.state_dict(), path)
         return self
 
 

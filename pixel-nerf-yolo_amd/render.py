@@ -132,16 +132,18 @@ class NeRFRenderer(torch.nn.Module):
         return res
 
     def sched_step(self, steps=1):
-        """reference nerf.py:324-344"""
+        """Sample-count schedule of the reference (nerf.py:324-344): sched = [iterations, n_coarse, n_fine];
+        once iter_idx passes sched[0][i] the renderer switches to (sched[1][i], sched[2][i])."""
         if self.sched is None:
             return
         self.iter_idx += steps
-        while (self.last_sched.item() < len(self.sched[0])
-               and self.iter_idx.item() >= self.sched[0][self.last_sched.item()]):
-            self.n_coarse = self.sched[1][self.last_sched.item()]
-            self.n_fine = self.sched[2][self.last_sched.item()]
+        milestones, coarse_counts, fine_counts = self.sched
+        stage = int(self.last_sched.item())
+        while stage < len(milestones) and int(self.iter_idx.item()) >= milestones[stage]:
+            self.n_coarse, self.n_fine = coarse_counts[stage], fine_counts[stage]
             print("INFO: NeRF sampling resolution changed on schedule ==> c", self.n_coarse, "f", self.n_fine)
-            self.last_sched += 1
+            stage += 1
+        self.last_sched.fill_(stage)
 
     @classmethod
     def from_conf(cls, conf, white_bkgd=False, lindisp=False, eval_batch_size=100000):
