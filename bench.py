@@ -9,16 +9,22 @@ bench.py -- rays/sec of the pixelNeRF-YOLO rendering hot path on MI355X (BASELIN
 Workload (BASELINE.json configs[1], "C2"): 128x128 render, 3 source views, ResNet-34 encoder,
 64 coarse + 32 fine samples (16 of them depth samples), white background; synthetic images,
 seeded random weights of the reference architecture, cameras on a sphere.
-A "step" = one full frame per rank (16384 rays resident in HBM -> rgb/depth in HBM): coarse
-sampling, fused MLP, composite, importance sampling + sort, fused MLP, composite, then (N > 1)
-one RCCL all-gather of the rendered (rays, 4) tiles.  Weak scaling: every rank renders its own
-frame; value = all rays of all ranks / max-over-ranks time.  The scene encode (ResNet-34 trunk)
-happens once per scene before the timed region and is reported as `encode_ms`.
+A "step" = one full frame per rank from resident inputs (source images + 16384 rays in HBM ->
+rgb/depth in HBM): scene encode (ResNet-34 trunk), latent projection (lin_z applied per latent pixel,
+see include/pnyolo.h), coarse sampling, fused MLP, composite, importance sampling + sort, fused MLP,
+composite, then (N > 1) one RCCL all-gather of the rendered (rays, 4) tiles.  Nothing is carried
+over between steps: the per-scene state (latent, projected maps) is rebuilt inside every timed step
+(the reference's eval loop encodes once per object and renders many views; this is the conservative
+reading).  Weak scaling: every rank renders its own frame; value = all rays of all ranks /
+max-over-ranks time.  `encode_ms` / `projection_ms` report the per-scene parts on their own.
 
 One JSON line on rank 0 with the contract fields plus
-  roofline:     dominant kernel = pny_mlp_kernel; achieved = algorithmic MLP FLOPs (2/MAC,
-                SURVEY.md 8d: 2.6218 GFLOP/ray) / its HIP-event time measured inside libpnyolo on
-                the launch stream; peak = 157.3 TFLOP/s exact-fp32 MFMA (the dtype issued).
+  roofline:     dominant kernel = pny_mlp_kernel; achieved = the GEMM FLOPs the kernel executes
+                (2/MAC, unpadded; DESIGN.md: 1.8668 GFLOP/ray with the projected latent, 2.6218
+                GFLOP/ray -- SURVEY.md 8d -- in the reference's operation order, --projection off)
+                / its HIP-event time measured inside libpnyolo on the launch stream; peak = 157.3
+                TFLOP/s exact-fp32 MFMA (the dtype issued).  `reference_order_tflops` prices the
+                same launches at the reference's FLOP count (not a utilisation figure).
   cpu_baseline: the oracle (oracle/pnyolo_oracle.py, a port) timed on the host cores on a bounded
                 ray subset of the same frame.
 """
@@ -38,8 +44,9 @@ FOCAL, Z_NEAR, Z_FAR = 131.25, 0.8, 1.8
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 
 
-def flop_per_ray():
-    per_vs = 42 * 512 + 3 * 512 * 512 + 6 * 512 * 512
+def flop_per_ray(projected=False):
+    """MLP GEMM FLOPs per ray: reference operation order, or with lin_z moved to the per-scene projection."""
+    per_vs = 42 * 512 + (0 if projected else 3 * 512 * 512) + 6 * 512 * 512
     post = 4 * 512 * 512 + 512 * 4
     per_sample = 2 * (NS * per_vs + post)
     return per_sample * (KC + (KC + KF))
@@ -48,6 +55,7 @@ def flop_per_ray():
 def describe():
     return {
         "metric": METRIC, "unit": "rays/s", "flop_per_ray": flop_per_ray(),
+        "flop_per_ray_projected": flop_per_ray(True),
         "config": {"workload": "C2: 128x128 render, 3 source views, ResNet34 encoder, 64 coarse + 32 fine "
                                "(16 depth) samples, white bkgd", "rays_per_step_per_gpu": H * W},
     }
@@ -59,6 +67,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cpu-rays", type=int, default=1536, help="ray subset for the CPU baseline (0 = skip)")
+    ap.add_argument("--projection", choices=["auto", "on", "off"], default="auto",
+                    help="latent projection mode of the fused MLP (off = the reference's operation order)")
     ap.add_argument("--describe", action="store_true", help="print the workload description and exit (no GPU)")
     args = ap.parse_args()
     if args.describe:
@@ -97,6 +107,7 @@ def main():
     sd.update(synth.resnet34_state(74))
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
     net = net.to(dev)
+    net.set_latent_projection(args.projection)
     src, _ = synth.scene_cameras(NS)
     tgt = synth.pose_spherical(120.0 + 10.0 * rank, -20.0, 1.3)
     images = torch.from_numpy(synth.images(75, NS, H, W)).to(dev)
@@ -113,6 +124,17 @@ def main():
         encode()
     torch.cuda.synchronize()
     encode_ms = (time.perf_counter() - t0) / 3 * 1e3
+    projection_ms = None
+    if args.projection != "off":
+        net.project_latent()
+        projection_ms = 0.0
+        for _ in range(3):
+            encode()                      # a new latent invalidates the projected maps
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            net.project_latent()          # coarse + fine maps
+            torch.cuda.synchronize()
+            projection_ms += (time.perf_counter() - t0) / 3 * 1e3
 
     rays = gen_rays(torch.from_numpy(tgt)[None].to(dev), W, H, focal, Z_NEAR, Z_FAR, c=c[0]).reshape(1, -1, 8)
     n_rays = rays.shape[1]
@@ -121,6 +143,7 @@ def main():
     gathered = torch.empty(world * n_rays, 4, device=dev) if world > 1 else None
 
     def step():
+        encode()                          # per-scene state is rebuilt inside the step (module docstring)
         with torch.no_grad():
             rgb, depth = par(rays)
         if world > 1:
@@ -140,15 +163,19 @@ def main():
     t0 = time.perf_counter()
     kern_ms = 0.0
     kern_flops = 0.0
+    ref_flops = 0.0
     launches = 0
+    projected = False
     for _ in range(args.steps):
         rgb, depth = step()
         # HIP-event times of this step's MLP launches (recorded on the launch stream inside
         # libpnyolo; reading them waits for the step, which the next step depends on anyway)
-        fl, ms, nl = net.last_mlp_stats()
-        kern_flops += fl
-        kern_ms += ms
-        launches += nl
+        st = net.last_mlp_stats(full=True)
+        kern_flops += st["flops"]
+        ref_flops += st["flops_reference"]
+        kern_ms += st["kernel_ms"]
+        launches += st["launches"]
+        projected = projected or st["projected"]
     fence()
     elapsed = time.perf_counter() - t0
     net.enable_kernel_timing(False)
@@ -168,14 +195,16 @@ def main():
         "config": dict(describe()["config"], n_views=NS, n_coarse=KC, n_fine=KF, n_fine_depth=KFD,
                        global_rays_per_step=world * n_rays,
                        parallelism="rays sharded, 1 process/GPU, dp%d, 1 all-gather/frame" % world),
-        "encode_ms": encode_ms,
-        "flop_per_ray": flop_per_ray(),
+        "encode_ms": encode_ms, "projection_ms": projection_ms,
+        "flop_per_ray": flop_per_ray(projected), "flop_per_ray_reference_order": flop_per_ray(False),
         "roofline": {
             "bound": "mfma", "kernel": "pny_mlp_kernel", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
             "unit": "TFLOP/s", "frac": (achieved / PEAK_F32_MFMA_TFLOPS) if achieved else None,
             "traffic": None, "launches": launches,
             "avg_launch_ms": (kern_ms / launches) if launches else None,
             "flops_per_launch": (kern_flops / launches) if launches else None,
+            "projected_latent": projected,
+            "reference_order_tflops": (ref_flops / (kern_ms * 1e-3) / 1e12) if kern_ms > 0 else None,
         },
     }
 

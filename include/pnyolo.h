@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PNY_ABI_VERSION 2
+#define PNY_ABI_VERSION 3
 
 typedef enum pny_status {
     PNY_OK = 0,
@@ -190,9 +190,30 @@ int pny_nms(const float* boxes_dev, int n, double iou_threshold, double threshol
 int pny_tp_fp_fn(const float* target_boxes_dev, int nt, const float* pred_boxes_dev, int np, double nms_iou,
                  double nms_threshold, double match_iou, int* out_dev, pny_stream stream);
 
-/* Introspection for bench.py: name and algorithmic FLOPs (2/MAC, MLP GEMMs only) of the last
- * pny_render / pny_query on this scene, and the HIP-event time of its MLP kernel launches. */
-int pny_scene_last_mlp_stats(pny_scene* s, double* flops, double* kernel_ms, int* launches);
+/* Latent projection.  `x = x + lin_z[b](z)` (src/model/resnetfc.py:176-182) with z the bilinear
+ * interpolation of the latent (src/model/encoder.py:101) is linear in the latent, so
+ * lin_z[b](interp(latent)) == interp(lin_z[b](latent)) up to fp32 rounding: with projection ON the
+ * library applies lin_z[b] to every latent PIXEL once per scene (cached until the latent or the
+ * weights change) and the fused kernel interpolates the projected maps instead of running the lin_z
+ * GEMMs per (sample, view).  Results stay inside the 1e-4 parity tolerance (tests/test_gpu_parity.py);
+ * OFF executes the reference's operation order.  AUTO (default; env PNYOLO_PROJECTION=off|on
+ * overrides at scene creation) projects when a launch has >= 2x as many points as the latent has
+ * pixels per view. */
+#define PNY_PROJECTION_OFF 0
+#define PNY_PROJECTION_ON 1
+#define PNY_PROJECTION_AUTO 2
+int pny_scene_set_projection(pny_scene* s, int mode);
+/* Compute the projected maps now (coarse, and fine when the model has one) instead of lazily inside
+ * the first large launch; a no-op when they are current.  Error when the mode is OFF. */
+int pny_scene_project(pny_scene* s, pny_stream stream);
+
+/* Introspection for bench.py: GEMM FLOPs (2/MAC, unpadded, MLP only) of the last pny_render /
+ * pny_query on this scene -- `flops` as executed by the fused kernel, `flops_reference` as the
+ * reference's operation order would execute them (equal when the projection is off) --, the HIP-event
+ * time of its MLP kernel launches (enable_timing), the launch count, and whether the last launch
+ * used the projected latent.  Any out pointer may be NULL. */
+int pny_scene_last_mlp_stats(pny_scene* s, double* flops, double* flops_reference, double* kernel_ms, int* launches,
+                             int* projected);
 int pny_scene_enable_timing(pny_scene* s, int enable);
 
 #ifdef __cplusplus

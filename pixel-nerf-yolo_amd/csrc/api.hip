@@ -64,6 +64,11 @@ struct pny_model {
     MlpWeights coarse{}, fine{};
     EncoderWeights enc;                       // folded conv+bn (encoder.h)
     bool has_encoder = false;
+    // lin_z[0..nvb) of the coarse / fine MLP stacked into one (nvb*512 x d_latent) pixel-wise map
+    ConvLayer zproj[2];
+    std::vector<float*> zproj_allocs;
+    bool has_zproj = false;
+    uint64_t generation = 0;                  // bumped by every finalize (scenes re-project)
 };
 
 struct pny_scene {
@@ -73,6 +78,13 @@ struct pny_scene {
     bool have_cams = false, have_latent = false;
     int cam_ns = 0;
     DevBuf cams, latent, work, scratch, enc_work;
+    // projected latent of the coarse [0] / fine [1] MLP (see ensure_projection)
+    DevBuf zp[2];
+    bool zp_valid[2] = {false, false};
+    uint64_t zp_generation = 0;
+    int zp_mode = PNY_PROJECTION_AUTO;
+    bool last_projected = false;
+    double last_flops_ref = 0.0;
     // timing of the MLP launches of the last call
     bool timing = false;
     std::vector<hipEvent_t> ev;
@@ -209,6 +221,7 @@ void pny_model_destroy(pny_model* m) {
     if (!m) return;
     m->packed.release();
     m->enc.release();
+    for (float* p : m->zproj_allocs) (void)hipFree(p);
     delete m;
 }
 
@@ -240,6 +253,26 @@ int pny_model_finalize(pny_model* m) {
     for (auto& f : plan.fix) *f.first = m->packed.f() + f.second;
     if (!m->desc.has_fine) m->fine = m->coarse;
     // encoder weights are optional (a scene may be fed through pny_scene_set_latent instead)
+    // stacked lin_z maps for the projected-latent variant
+    for (float* p : m->zproj_allocs) (void)hipFree(p);
+    m->zproj_allocs.clear();
+    m->has_zproj = false;
+    {
+        const int nvb = m->desc.combine_layer < m->desc.n_blocks ? m->desc.combine_layer : m->desc.n_blocks;
+        if (nvb > 0) {
+            for (int f = 0; f < (m->desc.has_fine ? 2 : 1); ++f) {
+                const std::string pre = f ? "mlp_fine." : "mlp_coarse.";
+                std::vector<const float*> mats;
+                for (int b = 0; b < nvb; ++b) mats.push_back(find(m, pre + "lin_z." + std::to_string(b) + ".weight")->data.data());
+                std::string err;
+                if (!build_pixel_linear(mats.data(), nvb, HID, m->desc.d_latent, &m->zproj[f], &m->zproj_allocs, &err))
+                    return fail(PNY_ERR_HIP, "latent projection weights: " + err);
+            }
+            if (!m->desc.has_fine) m->zproj[1] = m->zproj[0];
+            m->has_zproj = true;
+        }
+    }
+    ++m->generation;
     m->has_encoder = false;
     if (find(m, "encoder.model.conv1.weight")) {
         auto get = [&](const std::string& name, const float** data, std::vector<int64_t>* shape) -> bool {
@@ -267,6 +300,10 @@ int pny_scene_create(pny_scene** out, pny_model* m) {
     if (!out || !m) return fail(PNY_ERR_ARG, "pny_scene_create: null argument");
     pny_scene* s = new pny_scene();
     s->m = m;
+    if (const char* e = getenv("PNYOLO_PROJECTION")) {  // process-wide default: off | on | auto
+        if (!strcmp(e, "off")) s->zp_mode = PNY_PROJECTION_OFF;
+        if (!strcmp(e, "on")) s->zp_mode = PNY_PROJECTION_ON;
+    }
     *out = s;
     return PNY_OK;
 }
@@ -278,6 +315,8 @@ void pny_scene_destroy(pny_scene* s) {
     s->work.release();
     s->scratch.release();
     s->enc_work.release();
+    s->zp[0].release();
+    s->zp[1].release();
     for (auto e : s->ev) (void)hipEventDestroy(e);
     delete s;
 }
@@ -337,6 +376,7 @@ int pny_scene_set_latent(pny_scene* s, const float* latent_dev, int ns, int chan
     s->hl = hl;
     s->wl = wl;
     s->have_latent = true;
+    s->zp_valid[0] = s->zp_valid[1] = false;
     return PNY_OK;
 }
 
@@ -361,6 +401,7 @@ int pny_scene_encode(pny_scene* s, const float* images_dev, int ns, int height, 
     s->hl = hl;
     s->wl = wl;
     s->have_latent = true;
+    s->zp_valid[0] = s->zp_valid[1] = false;
     return PNY_OK;
 }
 
@@ -472,12 +513,44 @@ static int check_ready(pny_scene* s, const char* who) {
     return 0;
 }
 
-static double mlp_flops_per_point(const pny_model_desc& d, int ns) {
+static int view_blocks(const pny_model_desc& d) { return d.combine_layer < d.n_blocks ? d.combine_layer : d.n_blocks; }
+
+// GEMM FLOPs (2 per MAC, unpadded) per query point: as the reference computes it (with_lin_z) or as the
+// projected-latent variant executes it (lin_z moved to the per-scene projection).
+static double mlp_flops_per_point(const pny_model_desc& d, int ns, bool with_lin_z) {
     const int d_in = 3 + 6 * d.num_freqs + 3;
-    const int nvb = d.combine_layer < d.n_blocks ? d.combine_layer : d.n_blocks;
-    const double per_view = (double)d_in * HID + (double)nvb * d.d_latent * HID + 2.0 * nvb * HID * HID;
+    const int nvb = view_blocks(d);
+    const double per_view = (double)d_in * HID + (with_lin_z ? (double)nvb * d.d_latent * HID : 0.0) + 2.0 * nvb * HID * HID;
     const double post = 2.0 * (d.n_blocks - nvb) * HID * HID + (double)HID * d.d_out;
     return 2.0 * (ns * per_view + post);
+}
+
+// Projected latent: zp[v][y][x][b*512 + n] = sum_k lin_z[b].weight[n][k] * latent[v][y][x][k], computed
+// once per (scene latent, weights) on the caller's stream and cached.  AUTO uses it when the launch has
+// at least twice as many points as the latent has pixels per view (the projection costs one lin_z per
+// PIXEL instead of one per (sample, view); tiny training-size batches on large maps stay direct).
+static int ensure_projection(pny_scene* s, int which, long long n_points, hipStream_t st, const float** zp) {
+    *zp = nullptr;
+    const pny_model* m = s->m;
+    if (!m->has_zproj || s->zp_mode == PNY_PROJECTION_OFF) return 0;
+    if (s->zp_mode == PNY_PROJECTION_AUTO && n_points < 2ll * s->hl * s->wl) return 0;
+    const int nvb = view_blocks(m->desc);
+    if ((long long)s->hl * s->wl * nvb * HID >= (1ll << 31)) return 0;  // 32-bit tap offsets: stay direct
+    if (s->zp_generation != m->generation) {
+        s->zp_valid[0] = s->zp_valid[1] = false;
+        s->zp_generation = m->generation;
+    }
+    if (!m->desc.has_fine) which = 0;
+    if (!s->zp_valid[which]) {
+        const long long npix = (long long)s->ns * s->hl * s->wl;
+        int rc;
+        if ((rc = s->zp[which].reserve((size_t)npix * nvb * HID * sizeof(float)))) return rc;
+        if (!run_pixel_linear(m->zproj[which], s->latent.f(), npix, s->zp[which].f(), st))
+            return fail(PNY_ERR_HIP, "latent projection launch failed");
+        s->zp_valid[which] = true;
+    }
+    *zp = s->zp[which].f();
+    return 0;
 }
 
 static int run_mlp(pny_scene* s, int mode, const float* xyz, const float* dirs, const float* rays, const float* z,
@@ -486,8 +559,13 @@ static int run_mlp(pny_scene* s, int mode, const float* xyz, const float* dirs, 
     const pny_model_desc& d = s->m->desc;
     MlpArgs a;
     memset(&a, 0, sizeof(a));
-    a.w = (coarse || !d.has_fine || !s->m->use_fine) ? s->m->coarse : s->m->fine;
+    const bool fine_w = !(coarse || !d.has_fine || !s->m->use_fine);
+    a.w = fine_w ? s->m->fine : s->m->coarse;
     a.latent = s->latent.f();
+    int rc;
+    if ((rc = ensure_projection(s, fine_w ? 1 : 0, n_points, st, &a.zp))) return rc;
+    a.zp_stride = view_blocks(d) * HID;
+    a.tap_stride = a.zp ? a.zp_stride : s->L;
     a.cams = reinterpret_cast<const Cam*>(s->cams.p);
     a.xyz = xyz;
     a.dirs = dirs;
@@ -522,7 +600,6 @@ static int run_mlp(pny_scene* s, int mode, const float* xyz, const float* dirs, 
         if (g > 0 && g < grid) grid = g;
     }
     if (tiles < grid) grid = (int)tiles;
-    int rc;
     if ((rc = s->scratch.reserve(mlp_scratch_floats() * sizeof(float)))) return rc;
     a.scratch = s->scratch.f();
     if (s->timing) {
@@ -539,7 +616,9 @@ static int run_mlp(pny_scene* s, int mode, const float* xyz, const float* dirs, 
         PNY_HIP(hipEventRecord(s->ev[s->ev_used + 1], st));
         s->ev_used += 2;
     }
-    s->last_flops += mlp_flops_per_point(d, s->ns) * (double)n_points;
+    s->last_flops += mlp_flops_per_point(d, s->ns, a.zp == nullptr) * (double)n_points;
+    s->last_flops_ref += mlp_flops_per_point(d, s->ns, true) * (double)n_points;
+    s->last_projected = a.zp != nullptr;
     s->last_launches += 1;
     return 0;
 }
@@ -547,6 +626,7 @@ static int run_mlp(pny_scene* s, int mode, const float* xyz, const float* dirs, 
 static void begin_call(pny_scene* s) {
     s->ev_used = 0;
     s->last_flops = 0.0;
+    s->last_flops_ref = 0.0;
     s->last_launches = 0;
 }
 
@@ -683,9 +763,37 @@ int pny_scene_enable_timing(pny_scene* s, int enable) {
     return PNY_OK;
 }
 
-int pny_scene_last_mlp_stats(pny_scene* s, double* flops, double* kernel_ms, int* launches) {
+int pny_scene_set_projection(pny_scene* s, int mode) {
+    if (!s) return fail(PNY_ERR_ARG, "pny_scene_set_projection: null scene");
+    if (mode != PNY_PROJECTION_OFF && mode != PNY_PROJECTION_ON && mode != PNY_PROJECTION_AUTO)
+        return fail(PNY_ERR_ARG, "pny_scene_set_projection: mode must be PNY_PROJECTION_{OFF,ON,AUTO}");
+    s->zp_mode = mode;
+    return PNY_OK;
+}
+
+int pny_scene_project(pny_scene* s, pny_stream stream) {
+    int rc;
+    if ((rc = check_ready(s, "pny_scene_project"))) return rc;
+    if (!s->m->has_zproj) return PNY_OK;  // no per-view blocks: nothing to project
+    if (s->zp_mode == PNY_PROJECTION_OFF) return fail(PNY_ERR_STATE, "pny_scene_project: projection is switched off for this scene");
+    PNY_HIP(hipSetDevice(s->m->desc.device));
+    const int keep = s->zp_mode;
+    s->zp_mode = PNY_PROJECTION_ON;
+    const float* zp = nullptr;
+    rc = ensure_projection(s, 0, 0, (hipStream_t)stream, &zp);
+    if (!rc && s->m->desc.has_fine && s->m->use_fine) rc = ensure_projection(s, 1, 0, (hipStream_t)stream, &zp);
+    s->zp_mode = keep;
+    if (rc) return rc;
+    PNY_HIP(hipGetLastError());
+    return PNY_OK;
+}
+
+int pny_scene_last_mlp_stats(pny_scene* s, double* flops, double* flops_reference, double* kernel_ms, int* launches,
+                             int* projected) {
     if (!s) return fail(PNY_ERR_ARG, "pny_scene_last_mlp_stats: null scene");
     if (flops) *flops = s->last_flops;
+    if (flops_reference) *flops_reference = s->last_flops_ref;
+    if (projected) *projected = s->last_projected ? 1 : 0;
     if (launches) *launches = s->last_launches;
     if (kernel_ms) {
         double tot = 0.0;

@@ -30,6 +30,13 @@ struct EncoderWeights {
     void release();
 };
 
+// Pixel-wise linear map over a channel-last tensor, out[p][n] = sum_k W[n][k] in[p][k], run by the
+// same implicit-GEMM kernel as a 1x1 convolution (scale 1, shift 0, no relu).  `mats` are nmat
+// row-major (rows x k) matrices stacked along n; rows*nmat must be a multiple of 64, k of 8.
+bool build_pixel_linear(const float* const* mats, int nmat, int rows, int k, ConvLayer* out, std::vector<float*>* allocs,
+                        std::string* err);
+bool run_pixel_linear(const ConvLayer& L, const float* in, long long npix, float* out, hipStream_t st);
+
 void encoder_latent_size(int height, int width, int* hl, int* wl);
 size_t encoder_workspace_bytes(int ns, int height, int width, bool use_first_pool);
 // images (ns,3,H,W) NCHW -> latent (ns, H0, W0, 512) channel-last

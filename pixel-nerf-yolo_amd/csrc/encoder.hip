@@ -317,6 +317,33 @@ static bool build_conv(const EncoderWeights::Getter& get, const std::string& con
     return upload(pk, &L.w, allocs, err) && upload(sc, &L.scale, allocs, err) && upload(sh, &L.shift, allocs, err);
 }
 
+bool build_pixel_linear(const float* const* mats, int nmat, int rows, int k, ConvLayer* out, std::vector<float*>* allocs,
+                        std::string* err) {
+    const int cout = nmat * rows;
+    if (cout % 64 || k % 8) {
+        *err = "pixel-linear map needs rows*nmat % 64 == 0 and k % 8 == 0";
+        return false;
+    }
+    ConvLayer& L = *out;
+    L.cin = L.cin_p = k;
+    L.cout = cout;
+    L.k = 1;
+    L.stride = 1;
+    L.pad = 0;
+    L.J = k / 8;
+    std::vector<float> pk((size_t)(cout / 32) * L.J * 64 * 4);
+    size_t o = 0;
+    for (int nt = 0; nt < cout / 32; ++nt)
+        for (int j = 0; j < L.J; ++j)
+            for (int l = 0; l < 64; ++l) {
+                const int n = 32 * nt + (l & 31), kk = 8 * j + 4 * (l >> 5);
+                const float* row = mats[n / rows] + (size_t)(n % rows) * k + kk;
+                for (int r = 0; r < 4; ++r) pk[o++] = row[r];
+            }
+    const std::vector<float> one((size_t)cout, 1.0f), zero((size_t)cout, 0.0f);
+    return upload(pk, &L.w, *allocs, err) && upload(one, &L.scale, *allocs, err) && upload(zero, &L.shift, *allocs, err);
+}
+
 bool EncoderWeights::build(const Getter& get, const std::string& pre, std::string* err) {
     release();
     if (!build_conv(get, pre + "conv1", pre + "bn1", 3, 64, 7, 2, 3, conv1, allocs, err)) return false;
@@ -420,6 +447,11 @@ static bool run_conv(const ConvLayer& L, const float* in, int n, int hin, int wi
         hipLaunchKernelGGL(conv_mfma_kernel<1>, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, a);
     }
     return hipGetLastError() == hipSuccess;
+}
+
+bool run_pixel_linear(const ConvLayer& L, const float* in, long long npix, float* out, hipStream_t st) {
+    if (npix <= 0 || npix > 0x7fffffffll) return false;
+    return run_conv(L, in, 1, 1, (int)npix, nullptr, 0, out, st);
 }
 
 bool encoder_forward(const EncoderWeights& W, const float* images, int ns, int height, int width, bool use_first_pool,

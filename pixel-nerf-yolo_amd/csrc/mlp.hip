@@ -23,6 +23,12 @@
 //     (channel-last latent, 16-byte loads, 128-byte lines per 8 lanes), chunk-pipelined with the GEMM.
 //   * persistent over tiles; the cross-view running sum lives in a per-workgroup slab accessed
 //     non-temporally.
+//   * two instantiations: ZP = false runs lin_z per sample as written in the reference; ZP = true
+//     uses the per-scene projected latent (lin_z applied to every latent pixel once, api.hip
+//     ensure_projection): bilinear interpolation and lin_z are both linear, so
+//     lin_z(interp(latent)) = interp(lin_z(latent)) up to fp32 rounding, and the per-sample lin_z
+//     GEMMs (29 % of the FLOPs at L = 512, 64 % at L = 1792) become a 512-channel gather that is
+//     added to the residual stream in the epilogue that follows it anyway.
 #include <cstdlib>
 #include <cstring>
 
@@ -282,6 +288,35 @@ __device__ __forceinline__ void store_relu(const f32x16 (&acc)[NT][MT], float4* 
             }
 }
 
+// Projected-latent variant of the block entry: the LDS buffer holds the interpolated lin_z output in
+// the same [feature/4][m] layout; every lane reads the quads of ITS accumulator elements, adds them
+// to the residual stream and overwrites the same slots with relu(h) -- no other lane touches them.
+template <int NT, int MT>
+__device__ __forceinline__ void store_relu_addz(f32x16 (&acc)[NT][MT], float4* __restrict__ act, int wave, int lane) {
+    constexpr int TMc = 32 * MT;
+    const int m0 = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int kg = 8 * NT * wave + 8 * nt + 2 * q + hh;
+                float4* slot = act + kg * TMc + 32 * mt + m0;
+                const float4 zv = *slot;
+                acc[nt][mt][4 * q + 0] += zv.x;
+                acc[nt][mt][4 * q + 1] += zv.y;
+                acc[nt][mt][4 * q + 2] += zv.z;
+                acc[nt][mt][4 * q + 3] += zv.w;
+                float4 v;
+                v.x = fmaxf(acc[nt][mt][4 * q + 0], 0.f);
+                v.y = fmaxf(acc[nt][mt][4 * q + 1], 0.f);
+                v.z = fmaxf(acc[nt][mt][4 * q + 2], 0.f);
+                v.w = fmaxf(acc[nt][mt][4 * q + 3], 0.f);
+                *slot = v;
+            }
+}
+
 // Cross-view running sum slab (per workgroup, coalesced: register r of lane l at [r][l]).  It is
 // written and read with non-temporal accesses: 32 CUs x 128 KiB would otherwise evict the layer
 // weights from the XCD's 4 MiB L2 three times per tile.
@@ -309,8 +344,9 @@ __device__ __forceinline__ void slab_load(f32x16 (&t)[NT][MT], const float* slab
 // b_fc1 already contains the next block's lin_z bias (folded on the host, api.hip).
 // `after` is the weight segment that follows this block in the stream.  With slab != nullptr the
 // other views' running sum is fetched into the (then dead) net registers underneath the fc_1
-// GEMM and added to h afterwards.
-template <class C>
+// GEMM and added to h afterwards.  ADDZ: the LDS buffer holds this block's interpolated lin_z output
+// (projected-latent variant), added to h on entry.
+template <class C, bool ADDZ>
 __device__ __forceinline__ void res_block(f32x16 (&h)[C::NT][C::MT], WRing<C::WDEPTH, C::NT>& ring,
                                           const MlpWeights& w, int blk, const WSeg& after, float4* act, int wave,
                                           int lane, const float* slab ST_ARG) {
@@ -329,7 +365,10 @@ __device__ __forceinline__ void res_block(f32x16 (&h)[C::NT][C::MT], WRing<C::WD
         __syncthreads();
         const unsigned long long f1 = stamp_now();
         TRACE();  // ev B: past sync1
-        store_relu<NT, MT>(h, act, wave, lane);
+        if (ADDZ)
+            store_relu_addz<NT, MT>(h, act, wave, lane);
+        else
+            store_relu<NT, MT>(h, act, wave, lane);
         const unsigned long long f2 = stamp_now();
         __syncthreads();
         const unsigned long long f3 = stamp_now();
@@ -339,7 +378,10 @@ __device__ __forceinline__ void res_block(f32x16 (&h)[C::NT][C::MT], WRing<C::WD
         st.acc[ST_SYNC2] += f3 - f2;
 #else
         __syncthreads();
-        store_relu<NT, MT>(h, act, wave, lane);
+        if (ADDZ)
+            store_relu_addz<NT, MT>(h, act, wave, lane);
+        else
+            store_relu<NT, MT>(h, act, wave, lane);
         __syncthreads();
 #endif
         bias_apply<NT, MT, false>(net, bias);
@@ -483,7 +525,7 @@ __device__ __forceinline__ void prologue(const MlpArgs& a, int v, long long tile
             int off = 0;
             float wk = wgt[k];
             if (ok) {
-                off = ((int)ys[k] * a.Wl + (int)xs[k]) * a.L;
+                off = ((int)ys[k] * a.Wl + (int)xs[k]) * a.tap_stride;
             } else {
                 wk = wk * 0.0f;  // out-of-range tap contributes 0 (NaN coordinates stay NaN, as in ATen)
             }
@@ -506,7 +548,7 @@ __device__ __forceinline__ void prologue(const MlpArgs& a, int v, long long tile
 // the whole gather, so its four tap pointers / weights are set up once per (view, block).
 constexpr int GCH = 128;  // channels per gather chunk = 16 k-iterations of the lin_z GEMM
 
-template <class C>
+template <class C, int NB = 1>
 struct GatherTaps {
     static constexpr int NMB = C::TM / 8;           // sample blocks of 8
     static constexpr int QSTEP = C::NW / NMB;       // q-blocks (32 channels) covered per pass of all waves
@@ -514,15 +556,15 @@ struct GatherTaps {
     static_assert(QSTEP >= 1 && QPW >= 1 && QPW * QSTEP * 32 == GCH, "gather mapping");
     const float* t[4];  // tap base pointers (view, pixel, + 4*ql), channel 0
     float w[4];
-    float4 x[QPW][4];
+    float4 x[NB][QPW][4];  // NB chunks in flight
 };
 
-template <class C>
-__device__ __forceinline__ void gather_setup(GatherTaps<C>& g, const MlpArgs& a, int v, const int* tap_off,
+template <class C, int NB>
+__device__ __forceinline__ void gather_setup(GatherTaps<C, NB>& g, const float* view_base, const int* tap_off,
                                              const float* tap_w, int wave, int lane) {
     constexpr int TMc = C::TM, NMB = GatherTaps<C>::NMB;
     const int m = (wave % NMB) * 8 + (lane & 7);
-    const float* base = a.latent + (size_t)v * a.Hl * a.Wl * a.L + 4 * (lane >> 3);
+    const float* base = view_base + 4 * (lane >> 3);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         g.t[k] = base + tap_off[k * TMc + m];
@@ -530,35 +572,36 @@ __device__ __forceinline__ void gather_setup(GatherTaps<C>& g, const MlpArgs& a,
     }
 }
 
-template <class C>
-__device__ __forceinline__ void gather_issue(GatherTaps<C>& g, int c0, int wave) {
+template <class C, int B = 0, int NB>
+__device__ __forceinline__ void gather_issue(GatherTaps<C, NB>& g, int c0, int wave) {
     constexpr int NMB = GatherTaps<C>::NMB, QSTEP = GatherTaps<C>::QSTEP;
 #pragma unroll
     for (int i = 0; i < GatherTaps<C>::QPW; ++i) {
         const int qb = wave / NMB + i * QSTEP;  // q-block (8 quads = 32 channels) within the chunk
 #pragma unroll
-        for (int k = 0; k < 4; ++k) g.x[i][k] = *reinterpret_cast<const float4*>(g.t[k] + c0 + 32 * qb);
+        for (int k = 0; k < 4; ++k) g.x[B][i][k] = *reinterpret_cast<const float4*>(g.t[k] + c0 + 32 * qb);
     }
 }
 
-template <class C>
-__device__ __forceinline__ void gather_commit(const GatherTaps<C>& g, float4* act_win, int wave, int lane) {
+template <class C, int B = 0, int NB>
+__device__ __forceinline__ void gather_commit(const GatherTaps<C, NB>& g, float4* act_win, int wave, int lane) {
     constexpr int TMc = C::TM, NMB = GatherTaps<C>::NMB, QSTEP = GatherTaps<C>::QSTEP;
     const int m = (wave % NMB) * 8 + (lane & 7);
     float4* dst = act_win + (lane >> 3) * TMc + m;
 #pragma unroll
     for (int i = 0; i < GatherTaps<C>::QPW; ++i) {
         const int qb = wave / NMB + i * QSTEP;
+        const float4(&x)[4] = g.x[B][i];
         float4 r;  // ATen order: nw*w + ne*w + sw*w + se*w
-        r.x = ((g.x[i][0].x * g.w[0] + g.x[i][1].x * g.w[1]) + g.x[i][2].x * g.w[2]) + g.x[i][3].x * g.w[3];
-        r.y = ((g.x[i][0].y * g.w[0] + g.x[i][1].y * g.w[1]) + g.x[i][2].y * g.w[2]) + g.x[i][3].y * g.w[3];
-        r.z = ((g.x[i][0].z * g.w[0] + g.x[i][1].z * g.w[1]) + g.x[i][2].z * g.w[2]) + g.x[i][3].z * g.w[3];
-        r.w = ((g.x[i][0].w * g.w[0] + g.x[i][1].w * g.w[1]) + g.x[i][2].w * g.w[2]) + g.x[i][3].w * g.w[3];
+        r.x = ((x[0].x * g.w[0] + x[1].x * g.w[1]) + x[2].x * g.w[2]) + x[3].x * g.w[3];
+        r.y = ((x[0].y * g.w[0] + x[1].y * g.w[1]) + x[2].y * g.w[2]) + x[3].y * g.w[3];
+        r.z = ((x[0].z * g.w[0] + x[1].z * g.w[1]) + x[2].z * g.w[2]) + x[3].z * g.w[3];
+        r.w = ((x[0].w * g.w[0] + x[1].w * g.w[1]) + x[2].w * g.w[2]) + x[3].w * g.w[3];
         dst[(size_t)(8 * qb) * TMc] = r;
     }
 }
 
-template <class C>
+template <class C, bool ZP>
 __global__ __launch_bounds__(C::THREADS, C::WPS) void pny_mlp_kernel(const MlpArgs a) {
     constexpr int NT = C::NT, MT = C::MT, TMc = C::TM;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -580,7 +623,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void pny_mlp_kernel(const MlpAr
 
     const int n_view_blocks = a.combine_layer < a.n_blocks ? a.combine_layer : a.n_blocks;
     // weight segments of the stream (this wave's slices), in execution order:
-    //   per view: lin_in, then per view-block: lin_z chunks, fc_0, fc_1; then the post-combine blocks
+    //   per view: lin_in, then per view-block: lin_z chunks (ZP: none), fc_0, fc_1; then the post-combine blocks
     const WSeg s_in = wseg<NT>(a.w.w_in, D_IN_PAD / 8, 0, D_IN_PAD / 8, wave, lane);
     auto zseg = [&](int blk, int c0) { return wseg<NT>(a.w.w_z[blk], jz_tot, c0 / 8, GCH / 8, wave, lane); };
     auto fc0seg = [&](int blk) { return wseg<NT>(a.w.w_fc0[blk], 64, 0, 64, wave, lane); };
@@ -613,10 +656,33 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void pny_mlp_kernel(const MlpAr
             }
             {
                 ST_BEGIN();
-                gemm_run<C>(h, ring, s_in, n_view_blocks > 0 ? zseg(0, 0) : after_view(v), act, lane);
+                gemm_run<C>(h, ring, s_in, n_view_blocks > 0 ? (ZP ? fc0seg(0) : zseg(0, 0)) : after_view(v), act, lane);
                 ST_END(ST_GEMM);
             }
             for (int blk = 0; blk < n_view_blocks; ++blk) {
+                const bool last = (blk == n_view_blocks - 1);
+                if constexpr (ZP) {
+                    // x = x + interp(lin_z[blk](latent map)): the 512 projected channels of this block are
+                    // gathered into the whole LDS buffer (4 chunks, two in flight) and added to h by the
+                    // block entry below (store_relu_addz), which needs the barrier that follows anyway.
+                    constexpr int WIN = (GCH / 4) * TMc;
+                    GatherTaps<C, 2> g;
+                    ST_BEGIN();
+                    gather_setup<C>(g, a.zp + (size_t)v * a.Hl * a.Wl * a.zp_stride + blk * HID, tap_off, tap_w, wave, lane);
+                    gather_issue<C, 0>(g, 0, wave);
+                    gather_issue<C, 1>(g, GCH, wave);
+                    __builtin_amdgcn_sched_barrier(0);
+                    __syncthreads();  // every wave is done reading the buffer (previous GEMM)
+                    gather_commit<C, 0>(g, act, wave, lane);
+                    gather_issue<C, 0>(g, 2 * GCH, wave);
+                    gather_commit<C, 1>(g, act + WIN, wave, lane);
+                    gather_issue<C, 1>(g, 3 * GCH, wave);
+                    gather_commit<C, 0>(g, act + 2 * WIN, wave, lane);
+                    gather_commit<C, 1>(g, act + 3 * WIN, wave, lane);
+                    ST_END(ST_GATHER);
+                    res_block<C, true>(h, ring, a.w, blk, last ? after_view(v) : fc0seg(blk + 1), act, wave, lane,
+                                       (last && v > 0) ? slab : nullptr ST_PASS);
+                } else {
                 // x = x + lin_z[blk](z)  (reference resnetfc.py:176-182); bias folded upstream.
                 // GCH-channel chunks: the taps of chunk c+1 load while the MFMAs of chunk c run; chunk c
                 // lives in LDS window c % 4 (a window is rewritten 4 chunks = 3 barriers later).
@@ -624,7 +690,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void pny_mlp_kernel(const MlpAr
                     GatherTaps<C> g;
                     {
                         ST_BEGIN();
-                        gather_setup<C>(g, a, v, tap_off, tap_w, wave, lane);
+                        gather_setup<C>(g, a.latent + (size_t)v * a.Hl * a.Wl * a.L, tap_off, tap_w, wave, lane);
                         gather_issue<C>(g, 0, wave);
                         __builtin_amdgcn_sched_barrier(0);
                         __syncthreads();  // every wave is done reading the buffer (previous GEMM)
@@ -648,9 +714,9 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void pny_mlp_kernel(const MlpAr
                 }
                 // the last per-view block also folds in the running sum over the views done so far
                 // (reference util.py:489-499 combine_interleaved, mean over the NS views)
-                const bool last = (blk == n_view_blocks - 1);
-                res_block<C>(h, ring, a.w, blk, last ? after_view(v) : zseg(blk + 1, 0), act, wave, lane,
-                             (last && v > 0) ? slab : nullptr ST_PASS);
+                res_block<C, false>(h, ring, a.w, blk, last ? after_view(v) : zseg(blk + 1, 0), act, wave, lane,
+                                    (last && v > 0) ? slab : nullptr ST_PASS);
+                }
             }
             if (a.NS > 1) {
                 ST_BEGIN();
@@ -679,8 +745,8 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void pny_mlp_kernel(const MlpAr
             }
         }
         for (int blk = n_view_blocks; blk < a.n_blocks; ++blk)
-            res_block<C>(h, ring, a.w, blk, blk + 1 < a.n_blocks ? fc0seg(blk + 1) : s_in, act, wave, lane,
-                         nullptr ST_PASS);
+            res_block<C, false>(h, ring, a.w, blk, blk + 1 < a.n_blocks ? fc0seg(blk + 1) : s_in, act, wave, lane,
+                                nullptr ST_PASS);
 
         // out = lin_out(relu(h)) (reference resnetfc.py:185) + output head (models.py:312-317)
         ST_BEGIN();
@@ -743,11 +809,11 @@ int mlp_tile_samples() { return mlp_variant() == V_8x32 ? 32 : 64; }
 int mlp_max_grid() { return mlp_cu_count() * (mlp_variant() == V_8x32 ? 2 : 1); }
 size_t mlp_scratch_floats() { return (size_t)mlp_max_grid() * mlp_tile_samples() * HID; }
 
-template <class C>
+template <class C, bool ZP>
 static void launch_mlp_t(const MlpArgs& a, int grid, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pny_mlp_kernel<C>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pny_mlp_kernel<C, ZP>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
         attr_set = true;
     }
@@ -766,7 +832,7 @@ static void launch_mlp_t(const MlpArgs& a, int grid, hipStream_t st) {
     (void)hipMemsetAsync(tbuf, 0, (size_t)TRACE_WAVES * TRACE_N * sizeof(unsigned long long), st);
     (void)hipMemsetAsync(dbuf, 0, nst * sizeof(unsigned long long), st);
 #endif
-    hipLaunchKernelGGL(pny_mlp_kernel<C>, dim3(grid), dim3(C::THREADS), C::LDS, st, a);
+    hipLaunchKernelGGL((pny_mlp_kernel<C, ZP>), dim3(grid), dim3(C::THREADS), C::LDS, st, a);
 #ifdef PNY_STAMP
     {
         std::vector<unsigned long long> hst(nst);
@@ -795,11 +861,19 @@ static void launch_mlp_t(const MlpArgs& a, int grid, hipStream_t st) {
 #endif
 }
 
+template <class C>
+static void launch_mlp_c(const MlpArgs& a, int grid, hipStream_t st) {
+    if (a.zp)
+        launch_mlp_t<C, true>(a, grid, st);
+    else
+        launch_mlp_t<C, false>(a, grid, st);
+}
+
 void launch_mlp(const MlpArgs& a, int grid, hipStream_t st) {
     switch (mlp_variant()) {
-        case V_16x64: launch_mlp_t<Cfg<1, 2>>(a, grid, st); break;
-        case V_8x32: launch_mlp_t<Cfg<2, 1>>(a, grid, st); break;
-        default: launch_mlp_t<Cfg<2, 2>>(a, grid, st); break;
+        case V_16x64: launch_mlp_c<Cfg<1, 2>>(a, grid, st); break;
+        case V_8x32: launch_mlp_c<Cfg<2, 1>>(a, grid, st); break;
+        default: launch_mlp_c<Cfg<2, 2>>(a, grid, st); break;
     }
 }
 

@@ -40,6 +40,12 @@ struct MlpWeights {
 struct MlpArgs {
     MlpWeights w;
     const float* latent;  // (NS, Hl, Wl, L) channel-last
+    // Projected latent (NS, Hl, Wl, zp_stride = n_view_blocks*512): lin_z[b] applied to every latent
+    // pixel once per scene (api.hip ensure_projection).  Non-null selects the kernel variant that
+    // interpolates these maps instead of running the lin_z GEMMs per sample (both maps are linear).
+    const float* zp;
+    int zp_stride;
+    int tap_stride;       // floats per pixel of the map the taps address (L, or zp_stride)
     const Cam* cams;      // NS entries
     // point source: mode 0 = explicit points, mode 1 = rays + depths (point = o + z d)
     const float* xyz;

@@ -79,12 +79,16 @@ SIGNATURES = {
                           C.c_void_p]),
     "pny_tp_fp_fn": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double,
                                C.c_void_p, C.c_void_p]),
+    "pny_scene_set_projection": (C.c_int, [C.c_void_p, C.c_int]),
+    "pny_scene_project": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pny_scene_last_mlp_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
-                                           C.POINTER(C.c_int)]),
+                                           C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pny_scene_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
 }
 
 _lib = None
+ABI_VERSION = 3
+PROJECTION = {"off": 0, "on": 1, "auto": 2}
 
 
 class PnyError(RuntimeError):
@@ -119,7 +123,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.pny_version() != 2:
+    if lib.pny_version() != ABI_VERSION:
         raise PnyError("libpnyolo.so ABI version mismatch")
     _lib = lib
     return lib

@@ -220,6 +220,7 @@ class PixelNeRFNet(nn.Module):
         self._h_scenes = []
         self._synced_key = None
         self._timing = False
+        self._projection = None  # None = library default (auto, or env PNYOLO_PROJECTION)
 
     # ---------------------------------------------------------------- native plumbing
     def _device(self):
@@ -289,6 +290,8 @@ class PixelNeRFNet(nn.Module):
             s = C.c_void_p()
             check(L.pny_scene_create(C.byref(s), self._h_model))
             check(L.pny_scene_enable_timing(s, int(self._timing)))
+            if self._projection is not None:
+                check(L.pny_scene_set_projection(s, _lib.PROJECTION[self._projection]))
             self._h_scenes.append(s)
         return self._h_scenes[i]
 
@@ -298,17 +301,42 @@ class PixelNeRFNet(nn.Module):
         for s in self._h_scenes:
             check(_lib.load().pny_scene_enable_timing(s, int(on)))
 
-    def last_mlp_stats(self):
-        """(algorithmic FLOPs, kernel ms, launches) of the last call, summed over scenes."""
+    def set_latent_projection(self, mode):
+        """'auto' | 'on' | 'off' (include/pnyolo.h pny_scene_set_projection): whether the fused kernel
+        interpolates per-scene projected latent maps (lin_z applied once per latent pixel) or runs the
+        lin_z GEMMs per sample in the reference's operation order."""
+        if mode not in _lib.PROJECTION:
+            raise ValueError("latent projection mode must be one of %s" % sorted(_lib.PROJECTION))
+        self._projection = mode
+        for s in self._h_scenes:
+            check(_lib.load().pny_scene_set_projection(s, _lib.PROJECTION[mode]))
+        return self
+
+    def project_latent(self):
+        """Compute the projected maps of the encoded scenes now (otherwise done lazily by the first
+        large render call after encode)."""
+        self._sync()
+        for i in range(self.num_objs):
+            check(_lib.load().pny_scene_project(self._scene(i), stream_of(self._device())))
+        return self
+
+    def last_mlp_stats(self, full=False):
+        """(executed GEMM FLOPs, kernel ms, launches) of the last call, summed over scenes; with
+        full=True a dict that also carries the reference-order FLOP count and the projection flag."""
         L = _lib.load()
-        fl = ms = 0.0
+        fl = ref = ms = 0.0
         n = 0
+        proj = False
         for s in self._h_scenes[: max(self.num_objs, 1)]:
-            a, b, c = C.c_double(), C.c_double(), C.c_int()
-            check(L.pny_scene_last_mlp_stats(s, C.byref(a), C.byref(b), C.byref(c)))
+            a, r, b, c, p = C.c_double(), C.c_double(), C.c_double(), C.c_int(), C.c_int()
+            check(L.pny_scene_last_mlp_stats(s, C.byref(a), C.byref(r), C.byref(b), C.byref(c), C.byref(p)))
             fl += a.value
+            ref += r.value
             ms += b.value
             n += c.value
+            proj = proj or bool(p.value)
+        if full:
+            return dict(flops=fl, flops_reference=ref, kernel_ms=ms, launches=n, projected=proj)
         return fl, ms, n
 
     # ---------------------------------------------------------------- reference API

@@ -13,6 +13,10 @@ Importance sampling is discontinuous in the coarse weights (searchsorted on a cd
 difference upstream can move ONE fine sample to the neighbouring bin (hard part 5).
 Fine-pass checks therefore allow a bounded number of such rays and verify that every deviating
 ray really is a near-edge case.
+
+Every test that runs the fused MLP takes the `projection` fixture and runs twice: "off" (lin_z per
+sample, the reference's operation order) and "on" (per-scene projected latent, include/pnyolo.h
+pny_scene_set_projection) -- both variants must meet the same tolerances against the same goldens.
 """
 import numpy as np
 import pytest
@@ -30,6 +34,13 @@ from pixel_nerf_yolo_amd.util import gen_rays, gen_rays_yolo
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 TOL = 1e-4
+
+
+@pytest.fixture(params=["off", "on"])
+def projection(request, monkeypatch):
+    """Library-wide default of new scenes (read at pny_scene_create)."""
+    monkeypatch.setenv("PNYOLO_PROJECTION", request.param)
+    return request.param
 
 
 def dt(x):
@@ -66,13 +77,16 @@ def test_gen_rays_golden(golden):
 
 # --------------------------------------------------------------------------- golden: model
 @pytest.mark.parametrize("name,seed", [("nerf_c1", 1), ("nerf_c2", 7)])
-def test_query_golden(golden, name, seed):
+def test_query_golden(golden, name, seed, projection):
     g = golden(name)
     net = nerf_net(g, seed)
     xyz, vd = dt(g["probe_xyz"])[None], dt(g["probe_viewdirs"])[None]
     with torch.no_grad():
         out_c = net(xyz, coarse=True, viewdirs=vd)[0]
     assert maxabs(out_c, g["probe_out_coarse"]) < TOL
+    st = net.last_mlp_stats(full=True)
+    assert st["projected"] == (projection == "on") and st["launches"] == 1
+    assert (st["flops"] < st["flops_reference"]) if projection == "on" else (st["flops"] == st["flops_reference"])
     if "probe_out_fine" in g:
         with torch.no_grad():
             out_f = net(xyz, coarse=False, viewdirs=vd)[0]
@@ -85,7 +99,7 @@ def test_query_golden(golden, name, seed):
 
 
 # --------------------------------------------------------------------------- golden: render
-def test_render_c1_golden(golden):
+def test_render_c1_golden(golden, projection):
     g = golden("nerf_c1")
     net = nerf_net(g, 1)
     ren = NeRFRenderer(n_coarse=32, n_fine=0, white_bkgd=True).eval()
@@ -109,7 +123,7 @@ def fine_flip_report(z_hip, z_ref, rays, weights_ref, u_fine, kc):
     return bad
 
 
-def test_render_c2_golden(golden):
+def test_render_c2_golden(golden, projection):
     g = golden("nerf_c2")
     net = nerf_net(g, 7)
     ren = NeRFRenderer(n_coarse=64, n_fine=32, n_fine_depth=16, depth_std=0.01, white_bkgd=True).eval()
@@ -220,7 +234,7 @@ def yolo_net(g):
     return net
 
 
-def test_yolo_render_golden(golden):
+def test_yolo_render_golden(golden, projection):
     g = golden("yolo_c3")
     net = yolo_net(g)
     assert net.d_out == 21 and net.mlp_fine is None
@@ -263,7 +277,7 @@ def test_encoder_golden(golden):
 
 # --------------------------------------------------------------------------- oracle, ragged sizes
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 257])
-def test_query_ragged_vs_oracle(golden, n):
+def test_query_ragged_vs_oracle(golden, n, projection):
     g = golden("nerf_c2")
     net = nerf_net(g, 7)
     sc = oracle_scene(g, 7)
@@ -395,7 +409,7 @@ def check_render(net, sc, rays, kc, kf, kfd, lindisp=False, white=True, max_flip
         assert "fine" not in out
 
 
-def test_lindisp_and_fine_count_edges():
+def test_lindisp_and_fine_count_edges(projection):
     net, sc, rays = small_scene()
     sub = rays[torch.arange(0, rays.shape[0], 11)[:90]]
     check_render(net, sc, sub, 16, 8, 4, lindisp=True)        # samples linear in disparity (nerf.py:120-121,152-153)
@@ -405,7 +419,7 @@ def test_lindisp_and_fine_count_edges():
     check_render(net, sc, sub[:1], 16, 8, 4)                  # a single ray
 
 
-def test_c4_sample_counts():
+def test_c4_sample_counts(projection):
     """BASELINE config 4 sampling (128 coarse + 64 fine, 32 depth): K = 192 > 2 wavefront chunks in
     the composite, LDS-resident sort of 192 depths."""
     net, sc, rays = small_scene(ns=3)
@@ -413,7 +427,7 @@ def test_c4_sample_counts():
     check_render(net, sc, sub, 128, 64, 32)
 
 
-def test_single_view_three_block_model():
+def test_single_view_three_block_model(projection):
     """conf/default.conf of the reference: n_blocks = 3, no combine_layer (single source view)."""
     c = pconf.default_mv()
     for k in ("mlp_coarse", "mlp_fine"):
@@ -423,7 +437,7 @@ def test_single_view_three_block_model():
     check_render(net, sc, rays[torch.arange(0, rays.shape[0], 13)[:70]], 16, 8, 4)
 
 
-def test_per_view_intrinsics_query():
+def test_per_view_intrinsics_query(projection):
     net, sc, _ = small_scene(ns=3, per_view_intrinsics=True, seed=70)
     rs = np.random.RandomState(3)
     xyz = rs.uniform(-0.5, 0.5, size=(130, 3)).astype(np.float32)
@@ -433,7 +447,7 @@ def test_per_view_intrinsics_query():
     assert maxabs(out, orc.query(sc, xyz, vd, coarse=True)) < TOL
 
 
-def test_super_batch_two_scenes():
+def test_super_batch_two_scenes(projection):
     """SB = 2: reference semantics are scene-major (models.py:102-112, nerf.py:197-201)."""
     ns, H, W = 2, 32, 32
     net = make_model(pconf.default_mv()["model"]).eval()
@@ -463,6 +477,58 @@ def test_super_batch_two_scenes():
     with torch.no_grad():
         q = net(torch.zeros(2, 5, 3, device=DEV), viewdirs=torch.ones(2, 5, 3, device=DEV))
     assert q.shape == (2, 5, 4)
+
+
+def test_projection_cache_follows_latent_and_weights(golden):
+    """The projected maps are per (latent, weights) state: a new latent, new weights, or dropping the
+    fine MLP must not leave stale maps behind.  AUTO engages by launch size."""
+    g = golden("nerf_c2")
+    net = nerf_net(g, 7)
+    net.set_latent_projection("on")
+    ns, H, W = int(g["NS"]), int(g["H"]), int(g["W"])
+    rs = np.random.RandomState(11)
+    xyz = rs.uniform(-0.5, 0.5, size=(200, 3)).astype(np.float32)
+    vd = rs.standard_normal((200, 3)).astype(np.float32)
+
+    def q(coarse):
+        with torch.no_grad():
+            return net(dt(xyz)[None], coarse=coarse, viewdirs=dt(vd)[None])[0]
+
+    sc = oracle_scene(g, 7)
+    assert maxabs(q(False), orc.query(sc, xyz, vd, coarse=False)) < TOL
+    # 1. new latent on the same scene handle
+    lat2 = synth.latent(999, ns, 512, H // 2, W // 2)
+    net.encode(torch.zeros(1, ns, 3, H, W), torch.from_numpy(g["src_poses"])[None], torch.tensor(float(g["focal"])),
+               c=torch.from_numpy(g["c"])[None], latent=torch.from_numpy(lat2))
+    sc2 = orc.Scene(synth.mlp_state(71), synth.mlp_state(72), lat2, g["src_poses"], g["focal"], g["c"][None], W, H)
+    assert maxabs(q(False), orc.query(sc2, xyz, vd, coarse=False)) < TOL
+    assert maxabs(q(True), orc.query(sc2, xyz, vd, coarse=True)) < TOL
+    # 2. new weights (re-finalize bumps the model generation)
+    load_mlp(net.mlp_fine, 555, 512, 4)
+    sc3 = orc.Scene(synth.mlp_state(71), synth.mlp_state(555), lat2, g["src_poses"], g["focal"], g["c"][None], W, H)
+    assert maxabs(q(False), orc.query(sc3, xyz, vd, coarse=False)) < TOL
+    # 3. explicit eager projection, then the fine MLP is dropped (eval.py:140): coarse maps are used
+    net.project_latent()
+    net.mlp_fine = None
+    assert maxabs(q(False), orc.query(sc3, xyz, vd, coarse=True)) < TOL
+    assert net.last_mlp_stats(full=True)["projected"]
+    # 4. AUTO: 200 points < 2 x 64 x 64 latent pixels -> direct; a 9000-point launch projects
+    net.set_latent_projection("auto")
+    q(True)
+    assert not net.last_mlp_stats(full=True)["projected"]
+    big = rs.uniform(-0.5, 0.5, size=(9000, 3)).astype(np.float32)
+    with torch.no_grad():
+        out_big = net(dt(big)[None], coarse=True, viewdirs=dt(np.tile(vd, (45, 1)))[None])[0]
+    assert net.last_mlp_stats(full=True)["projected"]
+    net.set_latent_projection("off")
+    with torch.no_grad():
+        out_big_direct = net(dt(big)[None], coarse=True, viewdirs=dt(np.tile(vd, (45, 1)))[None])[0]
+    assert not net.last_mlp_stats(full=True)["projected"]
+    assert maxabs(out_big, out_big_direct) < TOL
+    with pytest.raises(plib.PnyError):
+        net.project_latent()          # explicit projection while switched off is an error, not a no-op
+    with pytest.raises(ValueError):
+        net.set_latent_projection("sometimes")
 
 
 def test_empty_inputs_through_the_abi(golden):
