@@ -531,6 +531,39 @@ def test_projection_cache_follows_latent_and_weights(golden):
         net.set_latent_projection("sometimes")
 
 
+def test_projection_error_is_fp32_conditioning(golden, monkeypatch):
+    """On a badly conditioned scene (latent scaled x80 like a random-weight encoder's output: hidden
+    activations ~1e3, sigma ~1e3) NO fp32 evaluation order reproduces another to 1e-4 absolute.  Measured
+    against the same formulas in float64, the projected variant must be as accurate as the direct variant
+    and as the fp32 oracle (the reference's own operation order on the CPU)."""
+    g = golden("nerf_c2")
+    ns, H, W = int(g["NS"]), int(g["H"]), int(g["W"])
+    lat = synth.latent(7 * 10 + 3, ns, 512, H // 2, W // 2) * 80.0
+    net = nerf_net(g, 7)
+    net.encode(torch.zeros(1, ns, 3, H, W), torch.from_numpy(g["src_poses"])[None], torch.tensor(float(g["focal"])),
+               c=torch.from_numpy(g["c"])[None], latent=torch.from_numpy(lat))
+    rs = np.random.RandomState(5)
+    xyz = rs.uniform(-0.5, 0.5, size=(3000, 3)).astype(np.float32)
+    vd = rs.standard_normal((3000, 3)).astype(np.float32)
+    out = {}
+    for mode in ("off", "on"):
+        net.set_latent_projection(mode)
+        with torch.no_grad():
+            out[mode] = net(dt(xyz)[None], coarse=True, viewdirs=dt(vd)[None])[0].cpu().double()
+    mk = lambda: orc.Scene(synth.mlp_state(71), synth.mlp_state(72), lat, g["src_poses"], g["focal"], g["c"][None], W, H)
+    ref32 = orc.query(mk(), xyz, vd, coarse=True).double()
+    monkeypatch.setattr(orc, "f32", torch.float64)      # the oracle's formulas in float64 = exact-math reference
+    ref64 = orc.query(mk(), xyz, vd, coarse=True)
+    monkeypatch.undo()
+    assert float(ref64[:, 3].max()) > 100.0             # the scene really is in the large-activation regime
+    err = {k: (v - ref64).abs() for k, v in dict(out, oracle32=ref32).items()}
+    for col, name in ((slice(0, 3), "rgb"), (slice(3, 4), "sigma")):
+        e_off, e_on, e_orc = (float(err[k][:, col].max()) for k in ("off", "on", "oracle32"))
+        print("%s: |off-f64| %.2e  |on-f64| %.2e  |oracle32-f64| %.2e" % (name, e_off, e_on, e_orc))
+        assert e_on <= 2.0 * max(e_off, e_orc) + 1e-6, (name, e_off, e_on, e_orc)
+        assert e_off <= 2.0 * max(e_on, e_orc) + 1e-6, (name, e_off, e_on, e_orc)
+
+
 def test_empty_inputs_through_the_abi(golden):
     g = golden("nerf_c1")
     net = nerf_net(g, 1)
