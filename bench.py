@@ -185,6 +185,17 @@ def main():
         elapsed = float(tmax.item())
     assert bool(torch.isfinite(rgb).all()) and bool(torch.isfinite(depth).all())
 
+    # HBM-side traffic of the dominant kernel cannot be counted from inside this process: it is the
+    # committed rocprofv3 PMC measurement of the same command (tools/profile_gpu.sh -> profiles/mlp_traffic.json)
+    traffic = traffic_note = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "mlp_traffic.json")) as fh:
+            tj = json.load(fh)
+        if bool(tj.get("projected_latent")) == bool(projected):
+            traffic, traffic_note = tj["bytes_per_launch"], "%s: %s" % (tj["tag"], tj["method"])
+    except (OSError, ValueError, KeyError):
+        pass
+
     total_rays = world * n_rays * args.steps
     value = total_rays / elapsed
     achieved = kern_flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else None
@@ -200,7 +211,7 @@ def main():
         "roofline": {
             "bound": "mfma", "kernel": "pny_mlp_kernel", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
             "unit": "TFLOP/s", "frac": (achieved / PEAK_F32_MFMA_TFLOPS) if achieved else None,
-            "traffic": None, "launches": launches,
+            "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_note, "launches": launches,
             "avg_launch_ms": (kern_ms / launches) if launches else None,
             "flops_per_launch": (kern_flops / launches) if launches else None,
             "projected_latent": projected,

@@ -51,6 +51,32 @@ def main(tag):
         for cname, a in sorted(acc.items()):
             out.append(f"| {os.path.basename(p)} | {cname} | {a[1]/max(a[0],1):.6g} | {a[0]} |")
     os.makedirs("profiles", exist_ok=True)
+    # fabric-side bytes per MLP launch for bench.py's roofline.traffic (MI355X_MICROARCH.md, HBM section:
+    # (FETCH_SIZE + WRITE_SIZE) KB, FETCH_SIZE doubled on gfx950 for 16-B/lane streaming reads; the
+    # counters sit on the L2's memory side, so Infinity-Cache hits are included: an upper bound on HBM bytes)
+    import json
+    per = {}
+    names = set()
+    for cname, pdir in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+        tot = cnt = 0
+        for r in rows(os.path.join(src, pdir, "**", "*counter_collection.csv")):
+            if "pny_mlp_kernel" in r.get("Kernel_Name", "") and r["Counter_Name"] == cname:
+                tot += float(r["Counter_Value"])
+                cnt += 1
+                names.add(r["Kernel_Name"].split("(")[0])
+        per[cname] = tot / cnt if cnt else None
+    if per["FETCH_SIZE"] is not None and per["WRITE_SIZE"] is not None:
+        traffic = {"tag": tag, "kernels": sorted(names), "projected_latent": any(", true>" in n for n in names),
+                   "fetch_kb_per_launch": per["FETCH_SIZE"], "write_kb_per_launch": per["WRITE_SIZE"],
+                   "bytes_per_launch": (2.0 * per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024.0,
+                   "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, mean over the "
+                             "MLP dispatches; (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md (gfx950 "
+                             "halves FETCH_SIZE for 16-B/lane streams); L2 memory-side requests, Infinity-Cache "
+                             "hits included"}
+        with open(os.path.join("profiles", "mlp_traffic.json"), "w") as fh:
+            json.dump(traffic, fh, indent=1)
+        out.append("\nroofline.traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 = %.4g bytes per MLP launch "
+                   "(written to profiles/mlp_traffic.json)" % traffic["bytes_per_launch"])
     dst = os.path.join("profiles", tag + "_summary.md")
     with open(dst, "w") as fh:
         fh.write("\n".join(out) + "\n")
