@@ -317,26 +317,43 @@ __device__ __forceinline__ void store_relu_addz(f32x16 (&acc)[NT][MT], float4* _
             }
 }
 
-// Cross-view running sum slab (per workgroup, coalesced: register r of lane l at [r][l]).  It is
-// written and read with non-temporal accesses: 32 CUs x 128 KiB would otherwise evict the layer
-// weights from the XCD's 4 MiB L2 three times per tile.
+// Cross-view running sum slab (per workgroup, coalesced 16-byte accesses: register quad q of tile
+// position p of lane l at float4 index (4p + q)*64 + l).  It is written and read with non-temporal
+// accesses: 32 CUs x 128 KiB would otherwise evict the layer weights from the XCD's 4 MiB L2 three
+// times per tile.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int NT, int MT>
 __device__ __forceinline__ void slab_store(const f32x16 (&h)[NT][MT], float* slab) {
+    f32x4* s4 = reinterpret_cast<f32x4*>(slab);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(h[nt][mt][r], slab + ((nt * MT + mt) * 16 + r) * 64);
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v;
+                v.x = h[nt][mt][4 * q + 0];
+                v.y = h[nt][mt][4 * q + 1];
+                v.z = h[nt][mt][4 * q + 2];
+                v.w = h[nt][mt][4 * q + 3];
+                __builtin_nontemporal_store(v, s4 + ((nt * MT + mt) * 4 + q) * 64);
+            }
 }
 template <int NT, int MT>
 __device__ __forceinline__ void slab_load(f32x16 (&t)[NT][MT], const float* slab) {
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(slab);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) t[nt][mt][r] = __builtin_nontemporal_load(slab + ((nt * MT + mt) * 16 + r) * 64);
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = __builtin_nontemporal_load(s4 + ((nt * MT + mt) * 4 + q) * 64);
+                t[nt][mt][4 * q + 0] = v.x;
+                t[nt][mt][4 * q + 1] = v.y;
+                t[nt][mt][4 * q + 2] = v.z;
+                t[nt][mt][4 * q + 3] = v.w;
+            }
 }
 
 // One pre-activation residual block (reference resnetfc.py:53-62):
@@ -610,7 +627,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void pny_mlp_kernel(const MlpAr
     float* tap_w = reinterpret_cast<float*>(smem_raw + ACT_KG * TMc * 16 + 16 * TMc);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float* slab = a.scratch + (size_t)blockIdx.x * (TMc * HID) + (size_t)wave * (NT * MT * 16 * 64) + lane;
+    float* slab = a.scratch + (size_t)blockIdx.x * (TMc * HID) + (size_t)wave * (NT * MT * 16 * 64) + 4 * lane;
     const int jz_tot = a.L / 8;
 #ifdef PNY_STAMP
     StampCtx st;
