@@ -490,8 +490,8 @@ __device__ __forceinline__ float input_entry(int e, const float (&xr)[3], const 
 // Per (view, tile) prologue: B operand of lin_in into act k-groups 0..15, and the four bilinear
 // taps of every sample into the tap table.
 template <class C>
-__device__ __forceinline__ void prologue(const MlpArgs& a, int v, long long tile, float4* act, int* tap_off,
-                                         float* tap_w, int tid) {
+__device__ __forceinline__ void prologue(const MlpArgs& a, int v, long long tile, float4* act, float4* tap_tab,
+                                         int tid) {
     constexpr int TMc = C::TM, NPART = C::THREADS / TMc;
     const int m = tid % TMc, part = tid / TMc;
     long long s = tile * TMc + m;
@@ -536,20 +536,22 @@ __device__ __forceinline__ void prologue(const MlpArgs& a, int v, long long tile
         const float xs[4] = {x0, x1, x0, x1};
         const float ys[4] = {y0, y0, y1, y1};
         const bool cull = a.yolo && !(xc[2] < 0.0f);  // models.py:224,254-264: z >= 0 (or NaN) -> zero latent
+        int offs[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const bool ok = (xs[k] >= 0.f) && (xs[k] <= (float)(a.Wl - 1)) && (ys[k] >= 0.f) && (ys[k] <= (float)(a.Hl - 1));
-            int off = 0;
-            float wk = wgt[k];
+            offs[k] = 0;
             if (ok) {
-                off = ((int)ys[k] * a.Wl + (int)xs[k]) * a.tap_stride;
+                offs[k] = ((int)ys[k] * a.Wl + (int)xs[k]) * a.tap_stride;
             } else {
-                wk = wk * 0.0f;  // out-of-range tap contributes 0 (NaN coordinates stay NaN, as in ATen)
+                wgt[k] = wgt[k] * 0.0f;  // out-of-range tap contributes 0 (NaN coordinates stay NaN, as in ATen)
             }
-            if (cull || (a.yolo && (wk != wk))) wk = 0.0f;
-            tap_off[k * TMc + m] = off;
-            tap_w[k * TMc + m] = wk;
+            if (cull || (a.yolo && (wgt[k] != wgt[k]))) wgt[k] = 0.0f;
         }
+        // one 32-byte record per sample: {offset[4] (int bits), weight[4]}
+        tap_tab[2 * m] = make_float4(__int_as_float(offs[0]), __int_as_float(offs[1]), __int_as_float(offs[2]),
+                                     __int_as_float(offs[3]));
+        tap_tab[2 * m + 1] = make_float4(wgt[0], wgt[1], wgt[2], wgt[3]);
     }
 }
 
@@ -577,16 +579,20 @@ struct GatherTaps {
 };
 
 template <class C, int NB>
-__device__ __forceinline__ void gather_setup(GatherTaps<C, NB>& g, const float* view_base, const int* tap_off,
-                                             const float* tap_w, int wave, int lane) {
-    constexpr int TMc = C::TM, NMB = GatherTaps<C>::NMB;
+__device__ __forceinline__ void gather_setup(GatherTaps<C, NB>& g, const float* view_base, const float4* tap_tab,
+                                             int wave, int lane) {
+    constexpr int NMB = GatherTaps<C>::NMB;
     const int m = (wave % NMB) * 8 + (lane & 7);
     const float* base = view_base + 4 * (lane >> 3);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        g.t[k] = base + tap_off[k * TMc + m];
-        g.w[k] = tap_w[k * TMc + m];
-    }
+    const float4 o = tap_tab[2 * m], w = tap_tab[2 * m + 1];
+    g.t[0] = base + __float_as_int(o.x);
+    g.t[1] = base + __float_as_int(o.y);
+    g.t[2] = base + __float_as_int(o.z);
+    g.t[3] = base + __float_as_int(o.w);
+    g.w[0] = w.x;
+    g.w[1] = w.y;
+    g.w[2] = w.z;
+    g.w[3] = w.w;
 }
 
 template <class C, int B = 0, int NB>
@@ -623,8 +629,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void pny_mlp_kernel(const MlpAr
     constexpr int NT = C::NT, MT = C::MT, TMc = C::TM;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float4* act = reinterpret_cast<float4*>(smem_raw);
-    int* tap_off = reinterpret_cast<int*>(smem_raw + ACT_KG * TMc * 16);
-    float* tap_w = reinterpret_cast<float*>(smem_raw + ACT_KG * TMc * 16 + 16 * TMc);
+    float4* tap_tab = reinterpret_cast<float4*>(smem_raw + ACT_KG * TMc * 16);  // 32 bytes per sample
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* slab = a.scratch + (size_t)blockIdx.x * (TMc * HID) + (size_t)wave * (NT * MT * 16 * 64) + 4 * lane;
@@ -666,7 +671,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void pny_mlp_kernel(const MlpAr
                 bias_load<NT>(bias, a.w.b_in, wave, lane);  // b_in + b_z[0] (folded on the host)
                 __builtin_amdgcn_sched_barrier(0);
                 __syncthreads();
-                prologue<C>(a, v, tile, act, tap_off, tap_w, tid);
+                prologue<C>(a, v, tile, act, tap_tab, tid);
                 __syncthreads();
                 bias_apply<NT, MT, false>(h, bias);
                 ST_END(ST_PROLOGUE);
@@ -685,7 +690,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void pny_mlp_kernel(const MlpAr
                     constexpr int WIN = (GCH / 4) * TMc;
                     GatherTaps<C, 2> g;
                     ST_BEGIN();
-                    gather_setup<C>(g, a.zp + (size_t)v * a.Hl * a.Wl * a.zp_stride + blk * HID, tap_off, tap_w, wave, lane);
+                    gather_setup<C>(g, a.zp + (size_t)v * a.Hl * a.Wl * a.zp_stride + blk * HID, tap_tab, wave, lane);
                     gather_issue<C, 0>(g, 0, wave);
                     gather_issue<C, 1>(g, GCH, wave);
                     __builtin_amdgcn_sched_barrier(0);
@@ -707,7 +712,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void pny_mlp_kernel(const MlpAr
                     GatherTaps<C> g;
                     {
                         ST_BEGIN();
-                        gather_setup<C>(g, a.latent + (size_t)v * a.Hl * a.Wl * a.L, tap_off, tap_w, wave, lane);
+                        gather_setup<C>(g, a.latent + (size_t)v * a.Hl * a.Wl * a.L, tap_tab, wave, lane);
                         gather_issue<C>(g, 0, wave);
                         __builtin_amdgcn_sched_barrier(0);
                         __syncthreads();  // every wave is done reading the buffer (previous GEMM)
