@@ -594,6 +594,8 @@ static int run_mlp(pny_scene* s, int mode, const float* xyz, const float* dirs, 
     const long long tiles = (n_points + tm - 1) / tm;
     if (tiles > 0x7fffffffll) return fail(PNY_ERR_ARG, "too many points for one launch");
     a.n_tiles = (int)tiles;
+    a.idx32 = (tiles * tm) < 0xffffffffll;
+    if (mode == 1 && (reinterpret_cast<uintptr_t>(rays) & 15)) return fail(PNY_ERR_ARG, "rays must be 16-byte aligned");
     int grid = mlp_max_grid();
     if (const char* e = getenv("PNYOLO_GRID")) {  // diagnostic: fewer resident workgroups
         const int g = atoi(e);

@@ -47,6 +47,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //   <NT=2, MT=2>:  8 waves, 256 VGPRs, 2 waves/SIMD, 64-sample tile, one workgroup per CU
 //   <NT=1, MT=2>: 16 waves, 128 VGPRs, 4 waves/SIMD, 64-sample tile, one workgroup per CU
 //   <NT=2, MT=1>:  8 waves, 128 VGPRs, 4 waves/SIMD, 32-sample tile, two workgroups per CU
+#ifndef PNY_WDEPTH
+#define PNY_WDEPTH 4  // 8 re-measured with the low-spill build: -1.1 %
+#endif
 template <int NT_, int MT_>
 struct Cfg {
     static constexpr int NT = NT_, MT = MT_;
@@ -54,7 +57,7 @@ struct Cfg {
     static constexpr int NW = 16 / NT;       // waves per workgroup
     static constexpr int THREADS = 64 * NW;
     static constexpr int WPS = (NT * MT == 4) ? 2 : 4;           // resident waves per SIMD (VGPR budget 512 / WPS)
-    static constexpr int WDEPTH = (NT == 2 && MT == 1) ? 2 : 4;  // weight-ring depth (k-iterations)
+    static constexpr int WDEPTH = (NT == 2 && MT == 1) ? 2 : PNY_WDEPTH;  // weight-ring depth (k-iterations)
     static constexpr int LDS = ACT_KG * TM * 16 + 32 * TM;       // activations + tap table
 };
 
@@ -459,14 +462,17 @@ __device__ __forceinline__ void load_point(const MlpArgs& a, long long s, float 
         }
     } else {
         // points = o + z * d (reference nerf.py:191), view dir = ray dir (nerf.py:210)
-        const long long ray = s / a.K;
-        const float* r = a.rays + ray * 8;
+        // (a 64-bit software division per thread is ~100 instructions: 32-bit whenever the launch fits)
+        const long long ray = a.idx32 ? (long long)((unsigned)s / (unsigned)a.K) : s / a.K;
+        const float4* r = reinterpret_cast<const float4*>(a.rays + ray * 8);  // rows are 32 bytes (api.hip checks alignment)
+        const float4 r0 = r[0], r1 = r[1];
         const float zz = a.z[s];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            d[i] = r[3 + i];
-            p[i] = r[i] + zz * d[i];
-        }
+        d[0] = r0.w;
+        d[1] = r1.x;
+        d[2] = r1.y;
+        p[0] = r0.x + zz * d[0];
+        p[1] = r0.y + zz * d[1];
+        p[2] = r0.z + zz * d[2];
     }
 }
 

@@ -57,6 +57,7 @@ struct MlpArgs {
     long long n_points;
     int K;            // samples per ray (mode 1)
     int mode;
+    int idx32;        // n_points (+ one tile) fits 32 bits: sample -> ray index with a 32-bit division
     int NS, L, Hl, Wl;
     int n_blocks, combine_layer, d_out, yolo, num_freqs;
     float freq_factor;
