@@ -248,6 +248,7 @@ int pny_model_finalize(pny_model* m) {
     PNY_HIP(hipDeviceSynchronize());  // a re-finalize must not overwrite weights a running kernel reads
     if ((rc = pack_mlp(m, "mlp_coarse.", m->coarse, plan))) return rc;
     if (m->desc.has_fine && (rc = pack_mlp(m, "mlp_fine.", m->fine, plan))) return rc;
+    if (plan.blob.size() * sizeof(float) >= (1ull << 31)) return fail(PNY_ERR_ARG, "packed weights exceed the 2 GiB raw-buffer range");
     if ((rc = m->packed.reserve(plan.blob.size() * sizeof(float)))) return rc;
     PNY_HIP(hipMemcpy(m->packed.p, plan.blob.data(), plan.blob.size() * sizeof(float), hipMemcpyHostToDevice));
     for (auto& f : plan.fix) *f.first = m->packed.f() + f.second;
@@ -561,6 +562,8 @@ static int run_mlp(pny_scene* s, int mode, const float* xyz, const float* dirs, 
     memset(&a, 0, sizeof(a));
     const bool fine_w = !(coarse || !d.has_fine || !s->m->use_fine);
     a.w = fine_w ? s->m->fine : s->m->coarse;
+    a.w_base = s->m->packed.f();
+    a.w_bytes = (unsigned)s->m->packed.bytes;
     a.latent = s->latent.f();
     int rc;
     if ((rc = ensure_projection(s, fine_w ? 1 : 0, n_points, st, &a.zp))) return rc;

@@ -111,8 +111,11 @@ __device__ __forceinline__ void trace_ev(StampCtx& c) {
 //     W[32*nt_global + m0][8j + 4hh + 0..3].
 
 // One k-iteration (8 input features = 4 MFMA k-steps) of the wave's NT x MT tile.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 template <int NT, int MT>
-__device__ __forceinline__ void mfma_iter(f32x16 (&acc)[NT][MT], const float4 (&a)[NT], const float4 (&b)[MT]) {
+__device__ __forceinline__ void mfma_iter(f32x16 (&acc)[NT][MT], const f32x4 (&a)[NT], const float4 (&b)[MT]) {
 #define PNY_STEP(c)                                                                                   \
     _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                 \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                             \
@@ -131,41 +134,62 @@ __device__ __forceinline__ void mfma_iter(f32x16 (&acc)[NT][MT], const float4 (&
 // with the head of the next layer's slice (WSeg next), so neither the epilogue/barrier phase nor the
 // head of a GEMM waits on memory.
 // Packed layout (api.hip pack_layer): k-iteration-major, [j][n-tile 0..15][lane] float4.
-struct WSeg {  // this wave's slice of one packed layer: fragment j of its n-tile t at w[(j*16 + t)*64]
-    const float4* w;
-    int jtot;  // (unused by the k-iteration-major layout; kept for segment bookkeeping)
+// The packed weights of both MLPs are ONE allocation, addressed through a raw buffer resource: a fragment
+// load is buffer_load_dwordx4 with the resource in SGPRs, a loop-invariant lane offset (16*lane) in one
+// VGPR and the fragment's byte offset in an SGPR -- the per-iteration address arithmetic is SALU only.
+// (With per-lane 64-bit pointers it was ~6 VALU instructions per k-iteration, and VALU issue takes cycles
+// from the fp32 MFMA pipe, tools/ubench/mfma_valu_coexec.hip.)  The wave index comes through
+// readfirstlane so that segment offsets are provably wave-uniform.  Out-of-range reads return 0.
+struct WSeg {  // this wave's slice of one packed layer: fragment j of its n-tile t at off + ((j*16 + t)*64 + lane)*16
+    unsigned off;  // byte offset into the weight blob
+    int jtot;      // (unused by the k-iteration-major layout; kept for segment bookkeeping)
     int jn;
 };
+struct WStream {
+    __amdgpu_buffer_rsrc_t rsrc;
+    const char* base;
+    unsigned lane_off;
+};
+__device__ __forceinline__ WStream wstream(const MlpArgs& a, int lane) {
+    WStream w;
+    w.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w_base), 0, (int)a.w_bytes, 0x00020000);
+    w.base = reinterpret_cast<const char*>(a.w_base);
+    w.lane_off = 16u * (unsigned)lane;
+    return w;
+}
 template <int NT>
-__device__ __forceinline__ WSeg wseg(const float* packed, int jtot, int j0, int jn, int wave, int lane) {
+__device__ __forceinline__ WSeg wseg(const WStream& ws, const float* packed, int jtot, int j0, int jn, int wave) {
     WSeg s;
-    s.w = reinterpret_cast<const float4*>(packed) + ((size_t)j0 * 16 + NT * wave) * 64 + lane;
+    s.off = (unsigned)(reinterpret_cast<const char*>(packed) - ws.base) + (unsigned)((j0 * 16 + NT * wave) * 64) * 16u;
     s.jtot = jtot;
     s.jn = jn;
     return s;
 }
-// fragment (k-iteration j, local n-tile nt) of a segment
-__device__ __forceinline__ const float4* wfrag(const WSeg& s, int nt, int j) { return s.w + ((size_t)j * 16 + nt) * 64; }
+// fragment (k-iteration j, local n-tile nt) of a segment, this lane's 16 bytes
+__device__ __forceinline__ f32x4 wload(const WStream& ws, unsigned seg_off, int nt, int j) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.lane_off, seg_off + (unsigned)((j * 16 + nt) * 64) * 16u, 0);
+    return __builtin_bit_cast(f32x4, v);
+}
 
 template <int D, int NT>
 struct WRing {
-    float4 f[D][NT];
+    f32x4 f[D][NT];
 #ifdef PNY_EXP_FOOT  // timing-only experiment: stream cyclically through the first PNY_EXP_FOOT k-iterations
-    const float4* exp_base;  // (16 KiB each) of the packed blob instead of the real layers (wrong results)
+    unsigned exp_base;  // (16 KiB each) of the packed blob instead of the real layers (wrong results)
     int exp_ctr;
 #endif
 };
 
 template <int D, int NT>
-__device__ __forceinline__ void ring_fill(WRing<D, NT>& r, const WSeg& s) {
+__device__ __forceinline__ void ring_fill(WRing<D, NT>& r, const WStream& ws, const WSeg& s) {
 #pragma unroll
     for (int d = 0; d + 1 < D; ++d) {  // slot D-1 is loaded by the segment's first step (gemm_run)
         const int j = d < s.jn ? d : s.jn - 1;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) r.f[d][nt] = *wfrag(s, nt, j);
+        for (int nt = 0; nt < NT; ++nt) r.f[d][nt] = wload(ws, s.off, nt, j);
     }
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) r.f[D - 1][nt] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int nt = 0; nt < NT; ++nt) r.f[D - 1][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
 // acc += W_slice * act over segment `cur`; leaves the ring holding the first WDEPTH-1 fragments of
@@ -180,8 +204,8 @@ __device__ __forceinline__ void ring_fill(WRing<D, NT>& r, const WSeg& s) {
 // Every segment length is a multiple of the depth (K padded accordingly on the host).
 // Activation fragments (LDS) alternate between two static slots, one iteration ahead.
 template <class C>
-__device__ __forceinline__ void gemm_run(f32x16 (&acc)[C::NT][C::MT], WRing<C::WDEPTH, C::NT>& r, const WSeg& cur,
-                                         const WSeg& next, const float4* __restrict__ act, int lane) {
+__device__ __forceinline__ void gemm_run(f32x16 (&acc)[C::NT][C::MT], WRing<C::WDEPTH, C::NT>& r, const WStream& ws,
+                                         const WSeg& cur, const WSeg& next, const float4* __restrict__ act, int lane) {
     constexpr int NT = C::NT, MT = C::MT, TMc = C::TM, WDEPTH = C::WDEPTH;
     const int m0 = lane & 31, hh = lane >> 5;
     const float4* bp = act + hh * TMc + m0;
@@ -200,7 +224,7 @@ __device__ __forceinline__ void gemm_run(f32x16 (&acc)[C::NT][C::MT], WRing<C::W
             const int jj = jd - 1 + WDEPTH;
             const bool in_cur = jj < jn;
             const int jx = in_cur ? jj : jj - jn;  // next.jn >= WDEPTH, so jx is in range
-            const float4* src = in_cur ? cur.w : next.w;
+            const unsigned src = in_cur ? cur.off : next.off;
             // (at jd == 0 this loads fragment WDEPTH-1 of this very segment: on entry the ring holds
             //  fragments 0 .. WDEPTH-2 only, so there is no special case at segment boundaries)
 #ifdef PNY_EXP_FOOT
@@ -210,11 +234,11 @@ __device__ __forceinline__ void gemm_run(f32x16 (&acc)[C::NT][C::MT], WRing<C::W
                 const int it = r.exp_ctr;
                 r.exp_ctr = (it + 1 == PNY_EXP_FOOT) ? 0 : it + 1;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) r.f[dp][nt] = r.exp_base[((size_t)it * 16 + nt) * 64];
+                for (int nt = 0; nt < NT; ++nt) r.f[dp][nt] = wload(ws, r.exp_base, nt, it);
             }
 #else
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) r.f[dp][nt] = src[((size_t)jx * 16 + nt) * 64];
+            for (int nt = 0; nt < NT; ++nt) r.f[dp][nt] = wload(ws, src, nt, jx);
 #endif
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) B[(d + 1) & 1][mt] = bp[(2 * j1) * TMc + 32 * mt];
@@ -324,7 +348,6 @@ __device__ __forceinline__ void store_relu_addz(f32x16 (&acc)[NT][MT], float4* _
 // position p of lane l at float4 index (4p + q)*64 + l).  It is written and read with non-temporal
 // accesses: 32 CUs x 128 KiB would otherwise evict the layer weights from the XCD's 4 MiB L2 three
 // times per tile.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int NT, int MT>
 __device__ __forceinline__ void slab_store(const f32x16 (&h)[NT][MT], float* slab) {
     f32x4* s4 = reinterpret_cast<f32x4*>(slab);
@@ -367,14 +390,14 @@ __device__ __forceinline__ void slab_load(f32x16 (&t)[NT][MT], const float* slab
 // GEMM and added to h afterwards.  ADDZ: the LDS buffer holds this block's interpolated lin_z output
 // (projected-latent variant), added to h on entry.
 template <class C, bool ADDZ>
-__device__ __forceinline__ void res_block(f32x16 (&h)[C::NT][C::MT], WRing<C::WDEPTH, C::NT>& ring,
+__device__ __forceinline__ void res_block(f32x16 (&h)[C::NT][C::MT], WRing<C::WDEPTH, C::NT>& ring, const WStream& ws,
                                           const MlpWeights& w, int blk, const WSeg& after, float4* act, int wave,
                                           int lane, const float* slab ST_ARG) {
     constexpr int NT = C::NT, MT = C::MT;
     f32x16 net[NT][MT];
     BiasRegs<NT> bias;
-    const WSeg s_fc0 = wseg<NT>(w.w_fc0[blk], 64, 0, 64, wave, lane);
-    const WSeg s_fc1 = wseg<NT>(w.w_fc1[blk], 64, 0, 64, wave, lane);
+    const WSeg s_fc0 = wseg<NT>(ws, w.w_fc0[blk], 64, 0, 64, wave);
+    const WSeg s_fc1 = wseg<NT>(ws, w.w_fc1[blk], 64, 0, 64, wave);
     {
         ST_BEGIN();
         bias_load<NT>(bias, w.b_fc0[blk], wave, lane);
@@ -409,7 +432,7 @@ __device__ __forceinline__ void res_block(f32x16 (&h)[C::NT][C::MT], WRing<C::WD
     }
     {
         ST_BEGIN();
-        gemm_run<C>(net, ring, s_fc0, s_fc1, act, lane);
+        gemm_run<C>(net, ring, ws, s_fc0, s_fc1, act, lane);
         ST_END(ST_GEMM);
         TRACE();  // ev D: end of GEMM fc0
     }
@@ -440,7 +463,7 @@ __device__ __forceinline__ void res_block(f32x16 (&h)[C::NT][C::MT], WRing<C::WD
     }
     {
         ST_BEGIN();
-        gemm_run<C>(h, ring, s_fc1, after, act, lane);
+        gemm_run<C>(h, ring, ws, s_fc1, after, act, lane);
         ST_END(ST_GEMM);
     }
     if (slab) {
@@ -637,7 +660,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void pny_mlp_kernel(const MlpAr
     float4* act = reinterpret_cast<float4*>(smem_raw);
     float4* tap_tab = reinterpret_cast<float4*>(smem_raw + ACT_KG * TMc * 16);  // 32 bytes per sample
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* slab = a.scratch + (size_t)blockIdx.x * (TMc * HID) + (size_t)wave * (NT * MT * 16 * 64) + 4 * lane;
     const int jz_tot = a.L / 8;
 #ifdef PNY_STAMP
@@ -652,9 +675,10 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void pny_mlp_kernel(const MlpAr
     const int n_view_blocks = a.combine_layer < a.n_blocks ? a.combine_layer : a.n_blocks;
     // weight segments of the stream (this wave's slices), in execution order:
     //   per view: lin_in, then per view-block: lin_z chunks (ZP: none), fc_0, fc_1; then the post-combine blocks
-    const WSeg s_in = wseg<NT>(a.w.w_in, D_IN_PAD / 8, 0, D_IN_PAD / 8, wave, lane);
-    auto zseg = [&](int blk, int c0) { return wseg<NT>(a.w.w_z[blk], jz_tot, c0 / 8, GCH / 8, wave, lane); };
-    auto fc0seg = [&](int blk) { return wseg<NT>(a.w.w_fc0[blk], 64, 0, 64, wave, lane); };
+    const WStream ws = wstream(a, lane);
+    const WSeg s_in = wseg<NT>(ws, a.w.w_in, D_IN_PAD / 8, 0, D_IN_PAD / 8, wave);
+    auto zseg = [&](int blk, int c0) { return wseg<NT>(ws, a.w.w_z[blk], jz_tot, c0 / 8, GCH / 8, wave); };
+    auto fc0seg = [&](int blk) { return wseg<NT>(ws, a.w.w_fc0[blk], 64, 0, 64, wave); };
     // segment that follows the per-view part of view v (after its last view-block)
     auto after_view = [&](int v) {
         if (v + 1 < a.NS) return s_in;
@@ -662,9 +686,9 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void pny_mlp_kernel(const MlpAr
         return s_in;  // next tile
     };
     WRing<C::WDEPTH, NT> ring;
-    ring_fill(ring, s_in);
+    ring_fill(ring, ws, s_in);
 #ifdef PNY_EXP_FOOT
-    ring.exp_base = s_in.w;
+    ring.exp_base = s_in.off;
     ring.exp_ctr = 0;
 #endif
 
@@ -684,7 +708,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void pny_mlp_kernel(const MlpAr
             }
             {
                 ST_BEGIN();
-                gemm_run<C>(h, ring, s_in, n_view_blocks > 0 ? (ZP ? fc0seg(0) : zseg(0, 0)) : after_view(v), act, lane);
+                gemm_run<C>(h, ring, ws, s_in, n_view_blocks > 0 ? (ZP ? fc0seg(0) : zseg(0, 0)) : after_view(v), act, lane);
                 ST_END(ST_GEMM);
             }
             for (int blk = 0; blk < n_view_blocks; ++blk) {
@@ -708,7 +732,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void pny_mlp_kernel(const MlpAr
                     gather_commit<C, 0>(g, act + 2 * WIN, wave, lane);
                     gather_commit<C, 1>(g, act + 3 * WIN, wave, lane);
                     ST_END(ST_GATHER);
-                    res_block<C, true>(h, ring, a.w, blk, last ? after_view(v) : fc0seg(blk + 1), act, wave, lane,
+                    res_block<C, true>(h, ring, ws, a.w, blk, last ? after_view(v) : fc0seg(blk + 1), act, wave, lane,
                                        (last && v > 0) ? slab : nullptr ST_PASS);
                 } else {
                 // x = x + lin_z[blk](z)  (reference resnetfc.py:176-182); bias folded upstream.
@@ -736,13 +760,13 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void pny_mlp_kernel(const MlpAr
                             ST_END(ST_GATHER);
                         }
                         ST_BEGIN();
-                        gemm_run<C>(h, ring, zseg(blk, c0), more ? zseg(blk, c0 + GCH) : fc0seg(blk), win, lane);
+                        gemm_run<C>(h, ring, ws, zseg(blk, c0), more ? zseg(blk, c0 + GCH) : fc0seg(blk), win, lane);
                         ST_END(ST_GEMM);
                     }
                 }
                 // the last per-view block also folds in the running sum over the views done so far
                 // (reference util.py:489-499 combine_interleaved, mean over the NS views)
-                res_block<C, false>(h, ring, a.w, blk, last ? after_view(v) : zseg(blk + 1, 0), act, wave, lane,
+                res_block<C, false>(h, ring, ws, a.w, blk, last ? after_view(v) : zseg(blk + 1, 0), act, wave, lane,
                                     (last && v > 0) ? slab : nullptr ST_PASS);
                 }
             }
@@ -773,7 +797,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void pny_mlp_kernel(const MlpAr
             }
         }
         for (int blk = n_view_blocks; blk < a.n_blocks; ++blk)
-            res_block<C, false>(h, ring, a.w, blk, blk + 1 < a.n_blocks ? fc0seg(blk + 1) : s_in, act, wave, lane,
+            res_block<C, false>(h, ring, ws, a.w, blk, blk + 1 < a.n_blocks ? fc0seg(blk + 1) : s_in, act, wave, lane,
                                 nullptr ST_PASS);
 
         // out = lin_out(relu(h)) (reference resnetfc.py:185) + output head (models.py:312-317)

@@ -39,6 +39,8 @@ struct MlpWeights {
 
 struct MlpArgs {
     MlpWeights w;
+    const float* w_base;  // the allocation all packed layers of `w` live in (raw-buffer addressing, mlp.hip)
+    unsigned w_bytes;
     const float* latent;  // (NS, Hl, Wl, L) channel-last
     // Projected latent (NS, Hl, Wl, zp_stride = n_view_blocks*512): lin_z[b] applied to every latent
     // pixel once per scene (api.hip ensure_projection).  Non-null selects the kernel variant that
