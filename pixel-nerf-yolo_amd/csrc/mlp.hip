@@ -613,7 +613,11 @@ __device__ __forceinline__ void gather_setup(GatherTaps<C, NB>& g, const float* 
     constexpr int NMB = GatherTaps<C>::NMB;
     const int m = (wave % NMB) * 8 + (lane & 7);
     const float* base = view_base + 4 * (lane >> 3);
-    const float4 o = tap_tab[2 * m], w = tap_tab[2 * m + 1];
+    float4 o = tap_tab[2 * m];
+    const float4 w = tap_tab[2 * m + 1];
+#if defined(PNY_EXP_GATHER) && PNY_EXP_GATHER == 1  // timing only: every tap reads pixel 0 (wrong results)
+    o = make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
     g.t[0] = base + __float_as_int(o.x);
     g.t[1] = base + __float_as_int(o.y);
     g.t[2] = base + __float_as_int(o.z);
@@ -630,8 +634,13 @@ __device__ __forceinline__ void gather_issue(GatherTaps<C, NB>& g, int c0, int w
 #pragma unroll
     for (int i = 0; i < GatherTaps<C>::QPW; ++i) {
         const int qb = wave / NMB + i * QSTEP;  // q-block (8 quads = 32 channels) within the chunk
+#if defined(PNY_EXP_GATHER) && PNY_EXP_GATHER == 2  // timing only: no tap loads (wrong results)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g.x[B][i][k] = make_float4(g.w[k], (float)c0, (float)qb, 1.f);
+#else
 #pragma unroll
         for (int k = 0; k < 4; ++k) g.x[B][i][k] = *reinterpret_cast<const float4*>(g.t[k] + c0 + 32 * qb);
+#endif
     }
 }
 
