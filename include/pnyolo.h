@@ -147,11 +147,11 @@ typedef struct pny_render_out {
 } pny_render_out;
 
 /* NeRFRenderer.forward for one scene (src/render/nerf.py:257-309): rays_dev (n,8) =
- * [origin, dir, near, far]. */
+ * [origin, dir, near, far], 16-byte aligned (rows are read as two 16-byte words; PNY_ERR_ARG otherwise). */
 int pny_render(pny_scene* s, const float* rays_dev, int64_t n, const pny_render_opts* opts,
                const pny_render_out* out, pny_stream stream);
 
-/* YoloRenderer.forward (src/render/yolo.py:37-114): coarse sampling only, raw (A*7)-vectors,
+/* YoloRenderer.forward (src/render/yolo.py:37-114): coarse sampling only, raw (A*7)-vectors, rays_dev 16-byte aligned,
  * out_dev (n, A, 7) = [max_k p, sum_k p v / (sum_k p + 1e-5)].  raw_dev (n,K,A*7) optional. */
 int pny_yolo_render(pny_scene* s, const float* rays_dev, int64_t n, int n_coarse, const float* u_coarse_dev,
                     uint64_t seed, float* out_dev, float* raw_dev, pny_stream stream);

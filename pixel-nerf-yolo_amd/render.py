@@ -85,6 +85,8 @@ class NeRFRenderer(torch.nn.Module):
         SB, B = rays.shape[0], rays.shape[1]
         assert SB == model.num_objs, "super-batch of rays must match the encoded scenes"
         rays = rays.detach().to(dev, torch.float32).contiguous()
+        if rays.data_ptr() % 16:
+            rays = rays.clone()  # the kernel reads a ray row as two 16-byte words
         kc, kf, kfd = int(self.n_coarse), int(self.n_fine), int(self.n_fine_depth)
         use_fine = self.using_fine and kf > 0
         if not use_fine:
@@ -199,6 +201,8 @@ class YoloRenderer(torch.nn.Module):
         L = _lib.load()
         dev = net._device()
         rays = rays.detach().to(dev, torch.float32).reshape(-1, 8).contiguous()
+        if rays.data_ptr() % 16:
+            rays = rays.clone()
         n = rays.shape[0]
         out = torch.empty(n, self.num_anchors_per_scale, 7, device=dev, dtype=torch.float32)
         draws, self.draws = self.draws, None

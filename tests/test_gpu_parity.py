@@ -564,6 +564,28 @@ def test_projection_error_is_fp32_conditioning(golden, monkeypatch):
         assert e_off <= 2.0 * max(e_on, e_orc) + 1e-6, (name, e_off, e_on, e_orc)
 
 
+def test_misaligned_rays_are_refused(golden):
+    """The fused kernel reads a ray row as two 16-byte words: an unaligned pointer is an argument error,
+    not a fault."""
+    g = golden("nerf_c1")
+    net = nerf_net(g, 1)
+    net._sync()
+    L = plib.load()
+    buf = torch.zeros(8 * 8 + 1, device=DEV)
+    rays = buf[1:].view(8, 8)                      # 4-byte offset from a 256-byte aligned allocation
+    rays.copy_(dt(g["rays"][:8]))
+    o = plib.RenderOpts(n_coarse=8, n_fine=0, n_fine_depth=0, depth_std=0.01, white_bkgd=1, lindisp=0, seed=1)
+    out = plib.RenderOut()
+    rgb, dep = torch.empty(8, 3, device=DEV), torch.empty(8, device=DEV)
+    out.rgb_coarse, out.depth_coarse = rgb.data_ptr(), dep.data_ptr()
+    import ctypes as C
+    rc = L.pny_render(net._scene(0), C.c_void_p(rays.data_ptr()), 8, C.byref(o), C.byref(out), plib.stream_of(torch.device(DEV)))
+    assert rc != 0 and b"16-byte aligned" in L.pny_last_error()
+    with torch.no_grad():                           # the aligned copy renders
+        ok = NeRFRenderer(n_coarse=8, n_fine=0, white_bkgd=True).eval()(net, rays.clone()[None])
+    assert bool(torch.isfinite(ok["coarse"]["rgb"]).all())
+
+
 def test_empty_inputs_through_the_abi(golden):
     g = golden("nerf_c1")
     net = nerf_net(g, 1)
