@@ -294,6 +294,15 @@ __device__ __forceinline__ void bias_apply(f32x16 (&acc)[NT][MT], const BiasRegs
             }
 }
 
+// relu as ONE v_max_f32 (fmaxf compiles to a canonicalising v_max x,x plus the max: 2 VALU per element,
+// 128 per epilogue, on the issue port the partner wave's MFMAs share).  Same result as fmaxf(x, 0.f)
+// for every input, NaN -> 0 included (IEEE mode: v_max returns the non-NaN operand).
+__device__ __forceinline__ float relu1(float x) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 // act[feature/4][m] = relu(acc): the next layer's B operand.
 template <int NT, int MT>
 __device__ __forceinline__ void store_relu(const f32x16 (&acc)[NT][MT], float4* __restrict__ act, int wave, int lane) {
@@ -306,10 +315,10 @@ __device__ __forceinline__ void store_relu(const f32x16 (&acc)[NT][MT], float4* 
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float4 v;
-                v.x = fmaxf(acc[nt][mt][4 * q + 0], 0.f);
-                v.y = fmaxf(acc[nt][mt][4 * q + 1], 0.f);
-                v.z = fmaxf(acc[nt][mt][4 * q + 2], 0.f);
-                v.w = fmaxf(acc[nt][mt][4 * q + 3], 0.f);
+                v.x = relu1(acc[nt][mt][4 * q + 0]);
+                v.y = relu1(acc[nt][mt][4 * q + 1]);
+                v.z = relu1(acc[nt][mt][4 * q + 2]);
+                v.w = relu1(acc[nt][mt][4 * q + 3]);
                 const int kg = 8 * NT * wave + 8 * nt + 2 * q + hh;
                 act[kg * TMc + 32 * mt + m0] = v;
             }
@@ -336,10 +345,10 @@ __device__ __forceinline__ void store_relu_addz(f32x16 (&acc)[NT][MT], float4* _
                 acc[nt][mt][4 * q + 2] += zv.z;
                 acc[nt][mt][4 * q + 3] += zv.w;
                 float4 v;
-                v.x = fmaxf(acc[nt][mt][4 * q + 0], 0.f);
-                v.y = fmaxf(acc[nt][mt][4 * q + 1], 0.f);
-                v.z = fmaxf(acc[nt][mt][4 * q + 2], 0.f);
-                v.w = fmaxf(acc[nt][mt][4 * q + 3], 0.f);
+                v.x = relu1(acc[nt][mt][4 * q + 0]);
+                v.y = relu1(acc[nt][mt][4 * q + 1]);
+                v.z = relu1(acc[nt][mt][4 * q + 2]);
+                v.w = relu1(acc[nt][mt][4 * q + 3]);
                 *slot = v;
             }
 }
