@@ -436,11 +436,14 @@ static bool run_conv(const ConvLayer& L, const float* in, int n, int hin, int wi
     // split K inside the workgroup when there are few tiles and a long reduction
     if (L.J >= 32 && tiles <= 512) {
         constexpr int lds = 8 * 4 * 16 * 64 * (int)sizeof(float);  // 128 KiB
-        static bool attr_set = false;
-        if (!attr_set) {
+        static bool attr_set[64] = {};  // per device: function attributes are per device
+        int dev_ = 0;
+        (void)hipGetDevice(&dev_);
+        dev_ &= 63;
+        if (!attr_set[dev_]) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<8>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            attr_set = true;
+            attr_set[dev_] = true;
         }
         hipLaunchKernelGGL(conv_mfma_kernel<8>, dim3((unsigned)tiles), dim3(512), lds, st, a);
     } else {

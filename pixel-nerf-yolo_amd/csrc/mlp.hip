@@ -881,11 +881,14 @@ size_t mlp_scratch_floats() { return (size_t)mlp_max_grid() * mlp_tile_samples()
 
 template <class C, bool ZP>
 static void launch_mlp_t(const MlpArgs& a, int grid, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};  // per device: function attributes are per device
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    dev_ &= 63;
+    if (!attr_set[dev_]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pny_mlp_kernel<C, ZP>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-        attr_set = true;
+        attr_set[dev_] = true;
     }
 #ifdef PNY_STAMP
     static unsigned long long* dbuf = nullptr;
