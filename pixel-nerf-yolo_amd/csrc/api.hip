@@ -593,13 +593,14 @@ static int run_mlp(pny_scene* s, int mode, const float* xyz, const float* dirs, 
     const float lsy = (float)s->hl / ((float)s->hl - 1.0f) * 2.0f;
     a.sx = lsx / (float)s->width;
     a.sy = lsy / (float)s->height;
-    const int tm = mlp_tile_samples();
+    const int variant = mlp_pick_variant(n_points);
+    const int tm = mlp_tile_samples(variant);
     const long long tiles = (n_points + tm - 1) / tm;
     if (tiles > 0x7fffffffll) return fail(PNY_ERR_ARG, "too many points for one launch");
     a.n_tiles = (int)tiles;
     a.idx32 = (tiles * tm) < 0xffffffffll;
     if (mode == 1 && (reinterpret_cast<uintptr_t>(rays) & 15)) return fail(PNY_ERR_ARG, "rays must be 16-byte aligned");
-    int grid = mlp_max_grid();
+    int grid = mlp_max_grid(variant);
     if (const char* e = getenv("PNYOLO_GRID")) {  // diagnostic: fewer resident workgroups
         const int g = atoi(e);
         if (g > 0 && g < grid) grid = g;
@@ -615,7 +616,7 @@ static int run_mlp(pny_scene* s, int mode, const float* xyz, const float* dirs, 
         }
         PNY_HIP(hipEventRecord(s->ev[s->ev_used], st));
     }
-    launch_mlp(a, grid, st);
+    launch_mlp(a, variant, grid, st);
     PNY_HIP(hipGetLastError());
     if (s->timing) {
         PNY_HIP(hipEventRecord(s->ev[s->ev_used + 1], st));

@@ -863,21 +863,30 @@ int mlp_cu_count() {
     return cus;
 }
 
-// PNYOLO_MLP_VARIANT selects the kernel shape: "8x64" (default), "16x64", "8x32" (see Cfg).
-enum MlpVariant { V_8x64 = 0, V_16x64 = 1, V_8x32 = 2 };
-static MlpVariant mlp_variant() {
-    static int v = -1;
-    if (v < 0) {
+// Kernel shape per launch.  PNYOLO_MLP_VARIANT forces "8x64", "16x64" or "8x32" (see Cfg); otherwise
+// 8x64 (fastest in steady state), except for launches too small to give every CU a 64-sample tile:
+// with at most half as many 64-sample tiles as CUs (training / visualisation batches, one YOLO view)
+// the 32-sample shape spreads the same work over twice as many CUs and the launch takes about half as long.
+static int forced_variant() {
+    static int v = -2;
+    if (v == -2) {
         const char* e = getenv("PNYOLO_MLP_VARIANT");
-        v = V_8x64;
-        if (e && !strcmp(e, "16x64")) v = V_16x64;
-        if (e && !strcmp(e, "8x32")) v = V_8x32;
+        v = -1;
+        if (e && !strcmp(e, "8x64")) v = MLP_8x64;
+        if (e && !strcmp(e, "16x64")) v = MLP_16x64;
+        if (e && !strcmp(e, "8x32")) v = MLP_8x32;
     }
-    return (MlpVariant)v;
+    return v;
 }
-int mlp_tile_samples() { return mlp_variant() == V_8x32 ? 32 : 64; }
-int mlp_max_grid() { return mlp_cu_count() * (mlp_variant() == V_8x32 ? 2 : 1); }
-size_t mlp_scratch_floats() { return (size_t)mlp_max_grid() * mlp_tile_samples() * HID; }
+int mlp_pick_variant(long long n_points) {
+    const int f = forced_variant();
+    if (f >= 0) return f;
+    const long long tiles64 = (n_points + 63) / 64;
+    return (2 * tiles64 <= mlp_cu_count()) ? MLP_8x32 : MLP_8x64;
+}
+int mlp_tile_samples(int variant) { return variant == MLP_8x32 ? 32 : 64; }
+int mlp_max_grid(int variant) { return mlp_cu_count() * (variant == MLP_8x32 ? 2 : 1); }
+size_t mlp_scratch_floats() { return (size_t)mlp_cu_count() * 64 * HID; }  // same for every shape
 
 template <class C, bool ZP>
 static void launch_mlp_t(const MlpArgs& a, int grid, hipStream_t st) {
@@ -942,10 +951,10 @@ static void launch_mlp_c(const MlpArgs& a, int grid, hipStream_t st) {
         launch_mlp_t<C, false>(a, grid, st);
 }
 
-void launch_mlp(const MlpArgs& a, int grid, hipStream_t st) {
-    switch (mlp_variant()) {
-        case V_16x64: launch_mlp_c<Cfg<1, 2>>(a, grid, st); break;
-        case V_8x32: launch_mlp_c<Cfg<2, 1>>(a, grid, st); break;
+void launch_mlp(const MlpArgs& a, int variant, int grid, hipStream_t st) {
+    switch (variant) {
+        case MLP_16x64: launch_mlp_c<Cfg<1, 2>>(a, grid, st); break;
+        case MLP_8x32: launch_mlp_c<Cfg<2, 1>>(a, grid, st); break;
         default: launch_mlp_c<Cfg<2, 2>>(a, grid, st); break;
     }
 }

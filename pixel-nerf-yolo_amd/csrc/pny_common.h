@@ -67,9 +67,11 @@ struct MlpArgs {
     int n_tiles;
 };
 
-void launch_mlp(const MlpArgs& a, int grid, hipStream_t st);
-int mlp_max_grid();        // resident workgroups = persistent grid size
-int mlp_tile_samples();    // samples per workgroup tile (32 or 64)
+enum { MLP_8x64 = 0, MLP_16x64 = 1, MLP_8x32 = 2 };  // kernel shapes (mlp.hip Cfg)
+int mlp_pick_variant(long long n_points);           // shape for a launch of n_points samples
+void launch_mlp(const MlpArgs& a, int variant, int grid, hipStream_t st);
+int mlp_max_grid(int variant);      // resident workgroups = persistent grid size
+int mlp_tile_samples(int variant);  // samples per workgroup tile (32 or 64)
 size_t mlp_scratch_floats();
 
 // render_kernels.hip

@@ -75,6 +75,28 @@ def c3():
     print("YOLO renderer (480 rays x 128 samples, one call): %.2f ms/view" % (dt * 1e3))
 
 
+def small():
+    """Training / visualisation-size launches (C2 scene): 128 rays x 64 coarse + 96 fine samples."""
+    c = pconf.default_mv()
+    net = make_model(c["model"]).eval()
+    load(net.mlp_coarse, 1, 512, 4)
+    load(net.mlp_fine, 2, 512, 4)
+    net = net.to(dev)
+    src, tgt = synth.scene_cameras(3)
+    focal, cc = torch.tensor(131.25), torch.tensor([[64.0, 64.0]])
+    net.encode(torch.zeros(1, 3, 3, 128, 128), torch.from_numpy(src)[None], focal, c=cc,
+               latent=torch.from_numpy(synth.latent(3, 3, 512, 64, 64)))
+    rays = gen_rays(torch.from_numpy(tgt)[None].to(dev), 128, 128, focal, 0.8, 1.8, c=cc[0]).reshape(1, -1, 8)
+    ren = NeRFRenderer(n_coarse=64, n_fine=32, n_fine_depth=16, white_bkgd=True).eval()
+    par = ren.bind_parallel(net, None, simple_output=True)
+    for n in (128, 256, 1024):
+        sub = rays[:, torch.arange(0, 16384, 16384 // n)[:n]].contiguous()
+        with torch.no_grad():
+            dt, _ = timed(lambda: par(sub), n=20)
+        print("render of %5d rays (64 + 96 samples): %.3f ms  (%.0f rays/s), MLP shape %s" % (
+            n, dt * 1e3, n / dt, os.environ.get("PNYOLO_MLP_VARIANT", "auto")))
+
+
 def c4():
     """400x400 render, 3 views, 128 coarse + 64 fine (32 depth), L=1792: one GPU's share and the full frame."""
     c = pconf.default_mv()
@@ -107,3 +129,5 @@ if __name__ == "__main__":
         c3()
     if "c4" in which:
         c4()
+    if "small" in which:
+        small()
