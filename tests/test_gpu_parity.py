@@ -354,6 +354,18 @@ def test_full_frame_properties():
     with torch.no_grad():
         s2 = ren(net, pad)
     assert torch.equal(s1["fine"]["rgb"][0], s2["fine"]["rgb"][0, 37:237])
+    # ... and across the per-launch kernel shapes: a 40-ray batch runs on 32-sample tiles (mlp_pick_variant), the
+    # 200-ray batch on 64-sample tiles; with the projection mode pinned the bits must still agree
+    net.set_latent_projection("on")
+    small = {k2: v[60:100] for k2, v in draws.items()}
+    ren.draws = draws
+    with torch.no_grad():
+        big = ren(net, sub)
+    ren.draws = small
+    with torch.no_grad():
+        few = ren(net, sub[:, 60:100].contiguous())
+    assert torch.equal(few["fine"]["rgb"][0], big["fine"]["rgb"][0, 60:100])
+    assert torch.equal(few["coarse"]["depth"][0], big["coarse"]["depth"][0, 60:100])
 
 
 # --------------------------------------------------------------------------- more configurations
