@@ -710,7 +710,22 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void pny_mlp_kernel(const MlpAr
     ring.exp_ctr = 0;
 #endif
 
-    for (long long tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    // XCD-aware tile order: workgroups are dispatched round-robin over the 8 XCDs (XCD = blockIdx % 8), each with
+    // its own L2.  XCD x walks the contiguous tile range [x*chunk, (x+1)*chunk): the 32 workgroups of an XCD then
+    // work on neighbouring rays at any moment, whose samples project onto overlapping pixels of the (projected)
+    // latent, instead of on every 8th ray.
+#ifndef PNY_NO_XCD_ORDER
+    const bool xcd_order = (gridDim.x & 7) == 0;
+#else
+    const bool xcd_order = false;
+#endif
+    const long long t_chunk = xcd_order ? (a.n_tiles + 7) / 8 : a.n_tiles;
+    const long long t_first = xcd_order ? (long long)(blockIdx.x & 7) * t_chunk + (blockIdx.x >> 3) : blockIdx.x;
+    const long long t_last = xcd_order ? ((long long)((blockIdx.x & 7) + 1) * t_chunk < a.n_tiles
+                                              ? (long long)((blockIdx.x & 7) + 1) * t_chunk : (long long)a.n_tiles)
+                                       : (long long)a.n_tiles;
+    const int t_step = xcd_order ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    for (long long tile = t_first; tile < t_last; tile += t_step) {
         f32x16 h[NT][MT];
         for (int v = 0; v < a.NS; ++v) {
             {
