@@ -576,6 +576,53 @@ def test_projection_error_is_fp32_conditioning(golden, monkeypatch):
         assert e_off <= 2.0 * max(e_on, e_orc) + 1e-6, (name, e_off, e_on, e_orc)
 
 
+def test_render_variants_golden(golden, projection):
+    """Reference goldens (tests/golden/nerf_variants.npz) for the renderer options and batch shapes the C1 / C2
+    fixtures do not exercise: lindisp + black background + importance-only fine pass; depth-only fine pass; a
+    2-scene super-batch with per-scene focal and principal point."""
+    g = golden("nerf_variants")
+    seed, ns, H, W = int(g["seed"]), int(g["NS"]), int(g["H"]), int(g["W"])
+
+    def build(lat, poses, focal, c):
+        net = make_model(pconf.default_mv()["model"]).eval()
+        load_mlp(net.mlp_coarse, seed * 10 + 1, 512, 4)
+        load_mlp(net.mlp_fine, seed * 10 + 2, 512, 4)
+        net = net.to(DEV)
+        sb = poses.shape[0]
+        net.encode(torch.zeros(sb, ns, 3, H, W), torch.from_numpy(poses), torch.from_numpy(np.asarray(focal)),
+                   c=torch.from_numpy(np.asarray(c)), latent=torch.from_numpy(lat))
+        return net
+
+    def check(prefix, out, flips=1):
+        for part in ("coarse", "fine"):
+            for k in ("rgb", "depth", "weights"):
+                ref = torch.from_numpy(g["%s%s_%s" % (prefix, part, k)])
+                got = out[part][k].cpu()
+                assert got.shape == ref.shape
+                bad = (got - ref).abs().reshape(got.shape[0] * got.shape[1], -1).max(dim=1)[0] > TOL
+                assert int(bad.sum()) <= (flips if part == "fine" else 0), (prefix, part, k, int(bad.sum()))
+
+    lat = synth.latent(int(g["ab_latent_seed"]), ns, 512, H // 2, W // 2)
+    net = build(lat, g["ab_poses"], g["ab_focal"], g["ab_c"])
+    ren = NeRFRenderer(n_coarse=16, n_fine=8, n_fine_depth=0, white_bkgd=False, lindisp=True).eval()
+    ren.draws = dict(u_coarse=g["a_draw0_rand_like"], u_fine=g["a_draw1_rand"], u_fine2=g["a_draw2_rand_like"],
+                     g_depth=np.zeros((24, 0), np.float32))
+    with torch.no_grad():
+        check("a_", ren(net, dt(g["a_rays"]), want_weights=True))
+    ren = NeRFRenderer(n_coarse=16, n_fine=8, n_fine_depth=8, white_bkgd=True).eval()
+    ren.draws = dict(u_coarse=g["b_draw0_rand_like"], u_fine=np.zeros((24, 0), np.float32),
+                     u_fine2=np.zeros((24, 0), np.float32), g_depth=g["b_draw1_randn_like"])
+    with torch.no_grad():
+        check("b_", ren(net, dt(g["b_rays"]), want_weights=True))
+    lat2 = np.concatenate([synth.latent(int(g["c_latent_seed"]) + i, ns, 512, H // 2, W // 2) for i in range(2)])
+    net2 = build(lat2, g["c_poses"], g["c_focal"], g["c_c"])
+    ren = NeRFRenderer(n_coarse=16, n_fine=8, n_fine_depth=4, white_bkgd=True).eval()
+    ren.draws = dict(u_coarse=g["c_draw0_rand_like"], u_fine=g["c_draw1_rand"], u_fine2=g["c_draw2_rand_like"],
+                     g_depth=g["c_draw3_randn_like"])
+    with torch.no_grad():
+        check("c_", ren(net2, dt(g["c_rays"]), want_weights=True))
+
+
 def test_misaligned_rays_are_refused(golden):
     """The fused kernel reads a ray row as two 16-byte words: an unaligned pointer is an argument error,
     not a fault."""

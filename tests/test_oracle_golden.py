@@ -165,3 +165,40 @@ def test_encoder_without_first_pool(golden):
     lat, levels = orc.spatial_encoder(sd, img, use_first_pool=False)
     assert lat.shape == g["latent"].shape and levels[1].shape[-2:] == levels[0].shape[-2:]
     assert maxabs(lat, g["latent"]) < 1e-6 * float(np.abs(g["latent"]).max())
+
+
+def _variant_scene(g, which, scene=0):
+    """Scenes of tests/golden/nerf_variants.npz (tools/make_golden.py fixture_nerf_variants)."""
+    from pixel_nerf_yolo_amd import synth
+    seed, ns, H, W = int(g["seed"]), int(g["NS"]), int(g["H"]), int(g["W"])
+    mc, mf = synth.mlp_state(seed * 10 + 1), synth.mlp_state(seed * 10 + 2)
+    if which == "ab":
+        lat = synth.latent(int(g["ab_latent_seed"]), ns, 512, H // 2, W // 2)
+        return orc.Scene(mc, mf, lat, g["ab_poses"][0], g["ab_focal"], g["ab_c"], W, H)
+    lat = synth.latent(int(g["c_latent_seed"]) + scene, ns, 512, H // 2, W // 2)
+    return orc.Scene(mc, mf, lat, g["c_poses"][scene], g["c_focal"][scene:scene + 1], g["c_c"][scene:scene + 1], W, H)
+
+
+def test_render_variants(golden):
+    """lindisp + black background + importance-only, depth-only fine pass, and a 2-scene super-batch with
+    per-scene intrinsics: the oracle against the reference's own outputs on the recorded draws."""
+    g = golden("nerf_variants")
+    sc = _variant_scene(g, "ab")
+    r = orc.render(sc, g["a_rays"][0], 16, 8, 0, g["a_draw0_rand_like"], g["a_draw1_rand"], g["a_draw2_rand_like"], None,
+                   white_bkgd=False, lindisp=True)
+    for part in ("coarse", "fine"):
+        for k, tol in (("rgb", 5e-6), ("depth", 5e-6), ("weights", 5e-6)):
+            assert maxabs(r[part][k], g["a_%s_%s" % (part, k)][0]) < tol, (part, k)
+    r = orc.render(sc, g["b_rays"][0], 16, 8, 8, g["b_draw0_rand_like"], None, None, g["b_draw1_randn_like"],
+                   white_bkgd=True, lindisp=False)
+    for part in ("coarse", "fine"):
+        for k in ("rgb", "depth", "weights"):
+            assert maxabs(r[part][k], g["b_%s_%s" % (part, k)][0]) < 5e-6, (part, k)
+    n = g["c_rays"].shape[1]
+    for i in range(2):                                   # the reference flattens (SB, B) scene-major
+        sl = slice(i * n, (i + 1) * n)
+        r = orc.render(_variant_scene(g, "c", i), g["c_rays"][i], 16, 8, 4, g["c_draw0_rand_like"][sl],
+                       g["c_draw1_rand"][sl], g["c_draw2_rand_like"][sl], g["c_draw3_randn_like"][sl])
+        for part in ("coarse", "fine"):
+            for k in ("rgb", "depth", "weights"):
+                assert maxabs(r[part][k], g["c_%s_%s" % (part, k)][i]) < 5e-6, (i, part, k)

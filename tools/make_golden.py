@@ -496,6 +496,75 @@ def fixture_yolo_tail(name, seed=9):
     print("wrote", name, {k: v.shape for k, v in cases.items() if "kept" in k or "tpfpfn" in k})
 
 
+def fixture_nerf_variants(name, seed=11):
+    """Renderer options and batch shapes the standard fixtures do not exercise, from the reference itself:
+      a_: lindisp=True, black background, importance samples only (n_fine_depth = 0)
+      b_: depth samples only (n_fine == n_fine_depth: no importance draws)
+      c_: super-batch of 2 scenes with per-scene focal (SB,2) and principal point (SB,2)."""
+    import util
+    from model import make_model
+    from render import NeRFRenderer
+
+    torch.manual_seed(seed)
+    H = W = 32
+    NS = 2
+    z_near, z_far = 0.8, 1.8
+    d = {"H": H, "W": W, "NS": NS, "seed": seed, "z_near": z_near, "z_far": z_far}
+
+    def build(SB, focal, c_img, lat_seed):
+        net = make_model(model_conf(has_fine=True)).eval()
+        load_mlp(net.mlp_coarse, seed * 10 + 1, 512, 4)
+        load_mlp(net.mlp_fine, seed * 10 + 2, 512, 4)
+        lat = np.concatenate([synth.latent(lat_seed + i, NS, 512, H // 2, W // 2) for i in range(SB)])
+        enc = net.encoder
+
+        def fake_forward(x):
+            enc.latent = torch.from_numpy(lat)
+            enc.latent_scaling[0] = enc.latent.shape[-1]
+            enc.latent_scaling[1] = enc.latent.shape[-2]
+            enc.latent_scaling = enc.latent_scaling / (enc.latent_scaling - 1) * 2.0
+            return enc.latent
+
+        enc.forward = fake_forward
+        poses = np.stack([synth.scene_cameras(NS, radius=1.3 + 0.2 * i)[0] for i in range(SB)])
+        net.encode(torch.zeros(SB, NS, 3, H, W), torch.from_numpy(poses), focal, c=c_img)
+        return net, lat, poses
+
+    def run(prefix, net, rays, **opts):
+        renderer = NeRFRenderer(depth_std=0.01, eval_batch_size=700, **opts).eval()
+        with torch.no_grad(), Recorder() as rec:
+            out = renderer(net, rays, want_weights=True)
+        d[prefix + "rays"] = np_(rays)
+        for i, (kind, t) in enumerate(rec.draws):
+            d["%sdraw%d_%s" % (prefix, i, kind)] = np_(t)
+        for part in ("coarse", "fine"):
+            for k in ("rgb", "depth", "weights"):
+                d["%s%s_%s" % (prefix, part, k)] = np_(out[part][k])
+
+    def some_rays(pose, focal, c, n, rs):
+        allr = util.gen_rays(torch.from_numpy(pose)[None], W, H, focal, z_near, z_far, c=c)[0].reshape(-1, 8)
+        return allr[torch.from_numpy(rs.choice(H * W, n, replace=False))]
+
+    rs = np.random.RandomState(seed)
+    focal1, c1 = torch.tensor(33.0), torch.tensor([[15.5, 16.5]])
+    net, lat, poses = build(1, focal1, c1, seed * 10 + 3)
+    d["ab_latent_seed"], d["ab_poses"], d["ab_focal"], d["ab_c"] = seed * 10 + 3, poses, np_(focal1), np_(c1)
+    tgt = synth.pose_spherical(110.0, -20.0, 1.3)
+    rays = some_rays(tgt, focal1, c1[0], 24, rs)[None]
+    run("a_", net, rays, n_coarse=16, n_fine=8, n_fine_depth=0, white_bkgd=False, lindisp=True)
+    run("b_", net, rays, n_coarse=16, n_fine=8, n_fine_depth=8, white_bkgd=True, lindisp=False)
+
+    focal2 = torch.tensor([[30.0, 30.0], [34.0, 33.0]])
+    c2 = torch.tensor([[16.0, 16.0], [15.0, 17.5]])
+    net2, lat2, poses2 = build(2, focal2, c2, seed * 10 + 5)
+    d["c_latent_seed"], d["c_poses"], d["c_focal"], d["c_c"] = seed * 10 + 5, poses2, np_(focal2), np_(c2)
+    rays2 = torch.stack([some_rays(synth.pose_spherical(100.0 + 30 * i, -20.0, 1.3), torch.tensor(31.0),
+                                   torch.tensor([16.0, 16.0]), 20, rs) for i in range(2)])
+    run("c_", net2, rays2, n_coarse=16, n_fine=8, n_fine_depth=4, white_bkgd=True, lindisp=False)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print("wrote", name, sorted(k for k in d if "draw" in k))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_shims()
@@ -508,6 +577,7 @@ def main():
     fixture_encoder("encoder", seed=4)
     fixture_yolo_tail("yolo_tail")
     fixture_encoder("encoder_nopool", seed=5, NS=1, H=48, W=32, use_first_pool=False)  # conf/exp/sn64.conf
+    fixture_nerf_variants("nerf_variants")
 
 
 if __name__ == "__main__":
