@@ -212,8 +212,13 @@ def index_latent(latent, uv, width, height):
     lat = latent.permute(0, 2, 3, 1).reshape(NS, Hl * Wl, L)
 
     def tap(xi, yi, w):
+        # Non-finite coordinates (0/0 or x/0 projections in YOLO mode) fail every bounds comparison: the tap reads
+        # nothing, but its weight is NaN and ATen's vectorised CPU kernel multiplies masked value * weight, so the
+        # sample comes out NaN (pinned by tests/golden/yolo_cull.npz: the reference reports "latent contains nan"
+        # and then zeroes those rows, models.py:262-264).
         ok = (xi >= 0) & (xi <= Wl - 1) & (yi >= 0) & (yi <= Hl - 1)
-        idx = (yi.clamp(0, Hl - 1) * Wl + xi.clamp(0, Wl - 1)).long()
+        zero = torch.zeros_like(xi)
+        idx = (torch.where(ok, yi, zero) * Wl + torch.where(ok, xi, zero)).long()
         v = torch.gather(lat, 1, idx.unsqueeze(-1).expand(-1, -1, L))
         return v * (w * ok.to(f32)).unsqueeze(-1)
 

@@ -623,6 +623,25 @@ def test_render_variants_golden(golden, projection):
         check("c_", ren(net2, dt(g["c_rays"]), want_weights=True))
 
 
+def test_yolo_latent_culling_golden(golden, projection):
+    """Reference golden for YOLO mode's latent culling (z_cam >= 0, NaN from 0/0 and inf projections): view 0 has
+    the identity extrinsic so the special camera-space coordinates are exact."""
+    g = golden("yolo_cull")
+    seed, ns = int(g["seed"]), int(g["NS"])
+    net = make_model(pconf.yolo()["model"]).eval()
+    load_mlp(net.mlp_coarse, seed * 10 + 1, 1792, 21)
+    net = net.to(DEV)
+    lat = torch.from_numpy(synth.latent(seed * 10 + 3, ns, 1792, int(g["Hl"]), int(g["Wl"])))
+    net.encode(torch.zeros(1, ns, 3, int(g["H"]), int(g["W"])), torch.from_numpy(g["w2c"])[None],
+               torch.from_numpy(g["focal"])[None], c=torch.from_numpy(g["c"])[None], latent=lat)
+    net.set_latent_projection(projection)      # 96 points: AUTO would stay direct
+    with torch.no_grad():
+        out = net(dt(g["xyz"])[None], coarse=True, viewdirs=dt(g["viewdirs"])[None])[0]
+    assert bool(torch.isfinite(out).all())
+    assert net.last_mlp_stats(full=True)["projected"] == (projection == "on")
+    assert maxabs(out, g["out"]) < TOL * max(1.0, float(np.abs(g["out"]).max()))
+
+
 def test_misaligned_rays_are_refused(golden):
     """The fused kernel reads a ray row as two 16-byte words: an unaligned pointer is an argument error,
     not a fault."""

@@ -202,3 +202,17 @@ def test_render_variants(golden):
         for part in ("coarse", "fine"):
             for k in ("rgb", "depth", "weights"):
                 assert maxabs(r[part][k], g["c_%s_%s" % (part, k)][i]) < 5e-6, (i, part, k)
+
+
+def test_yolo_latent_culling(golden):
+    """models.py:222-224,254-264: latent zeroed where z_cam >= 0 and where it is NaN (0/0, inf projections)."""
+    from pixel_nerf_yolo_amd import synth
+    g = golden("yolo_cull")
+    seed, ns = int(g["seed"]), int(g["NS"])
+    lat = synth.latent(seed * 10 + 3, ns, 1792, int(g["Hl"]), int(g["Wl"]))
+    sc = orc.Scene(synth.mlp_state(seed * 10 + 1, d_latent=1792, d_out=21), None, lat, g["w2c"], g["focal"][None],
+                   g["c"][None], int(g["W"]), int(g["H"]), yolo=True)
+    out = orc.query(sc, g["xyz"], g["viewdirs"], coarse=True)
+    assert bool(torch.isfinite(out).all())
+    scale = float(np.abs(g["out"]).max())
+    assert maxabs(out, g["out"]) < 2e-6 * max(1.0, scale)

@@ -565,6 +565,58 @@ def fixture_nerf_variants(name, seed=11):
     print("wrote", name, sorted(k for k in d if "draw" in k))
 
 
+def fixture_yolo_cull(name, seed=13):
+    """YOLO mode's latent culling (reference models.py:222-224,254-264): latent := 0 where z_cam >= 0 and where it
+    is NaN.  View 0 has the identity extrinsic so that camera-space coordinates are exact: the points include
+    z == 0 with x == y == 0 (0/0), z == 0 with x != 0 (+-inf uv), z > 0, z < 0 and far out-of-image projections."""
+    import model.encoder as enc_mod
+    from model import make_model
+
+    torch.manual_seed(seed)
+
+    class DummyYolo(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.dims = [1792]
+
+    enc_mod.YOLOEncoder = DummyYolo
+    net = make_model(model_conf(backbone="custom", yolo=True, has_fine=False)).eval()
+    load_mlp(net.mlp_coarse, seed * 10 + 1, 1792, 21)
+    NS, H, W, Hl, Wl = 2, 64, 64, 8, 8
+    lat = synth.latent(seed * 10 + 3, NS, 1792, Hl, Wl)
+    enc = net.encoder
+
+    def fake_forward(x):
+        enc.latent = torch.from_numpy(lat)
+        enc.latent_scaling[0] = enc.latent.shape[-1]
+        enc.latent_scaling[1] = enc.latent.shape[-2]
+        enc.latent_scaling = enc.latent_scaling / (enc.latent_scaling - 1) * 2.0
+        return enc.latent
+
+    enc.forward = fake_forward
+    src_c2w, _ = synth.scene_cameras(NS, radius=4.0, phi=-25.0)
+    flipyz = np.diag([1.0, -1.0, -1.0, 1.0]).astype(np.float32)
+    w2c = np.stack([np.eye(4, dtype=np.float32), np.linalg.inv(src_c2w[1] @ flipyz).astype(np.float32)])
+    focal, c_img = torch.tensor([40.0, 44.0]), torch.tensor([32.0, 30.0])
+    net.encode(torch.zeros(1, NS, 3, H, W), torch.from_numpy(w2c)[None], focal[None], c=c_img[None])
+    rs = np.random.RandomState(seed)
+    pts = rs.uniform(-3.0, 3.0, size=(96, 3)).astype(np.float32)
+    pts[0] = [0.0, 0.0, 0.0]        # view 0: 0/0
+    pts[1] = [0.5, 0.0, 0.0]        # view 0: +inf u, 0/0 v
+    pts[2] = [-0.5, 0.25, 0.0]      # view 0: -inf, +inf
+    pts[3] = [0.1, 0.1, 2.0]        # view 0: z > 0 -> culled
+    pts[4] = [0.1, 0.1, -2.0]       # view 0: z < 0 -> kept, projects inside the image
+    pts[5] = [50.0, -60.0, -0.5]    # view 0: far outside the image
+    pts[6] = [0.0, 0.0, -1e-30]     # view 0: tiny negative z
+    vd = rs.standard_normal((96, 3)).astype(np.float32)
+    with torch.no_grad():
+        out = net(torch.from_numpy(pts)[None], coarse=True, viewdirs=torch.from_numpy(vd)[None])[0]
+    d = {"seed": seed, "NS": NS, "H": H, "W": W, "Hl": Hl, "Wl": Wl, "w2c": w2c, "focal": np_(focal), "c": np_(c_img),
+         "xyz": pts, "viewdirs": vd, "out": np_(out)}
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print("wrote", name, d["out"].shape, "finite:", bool(np.isfinite(d["out"]).all()))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_shims()
@@ -578,6 +630,7 @@ def main():
     fixture_yolo_tail("yolo_tail")
     fixture_encoder("encoder_nopool", seed=5, NS=1, H=48, W=32, use_first_pool=False)  # conf/exp/sn64.conf
     fixture_nerf_variants("nerf_variants")
+    fixture_yolo_cull("yolo_cull")
 
 
 if __name__ == "__main__":
