@@ -123,6 +123,15 @@ def test_renderer_interface_and_sched():
     ren.n_coarse, ren.n_fine, ren.using_fine = 128, 0, False
 
 
+def test_sched_step_matches_reference(golden):
+    """tests/golden/sched.npz: the reference's NeRFRenderer driven through the same step sequence."""
+    g = golden("sched")
+    ren = NeRFRenderer(n_coarse=16, n_fine=4, sched=g["sched"].tolist())
+    for st, row in zip(g["steps"].tolist(), g["rows"].tolist()):
+        ren.sched_step(st)
+        assert [ren.n_coarse, ren.n_fine, int(ren.iter_idx), int(ren.last_sched)] == row
+
+
 def test_unsupported_configs_are_refused():
     c = pconf.default_mv()
     c.d["model"]["mlp_coarse"]["use_spade"] = True

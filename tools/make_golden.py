@@ -617,6 +617,20 @@ def fixture_yolo_cull(name, seed=13):
     print("wrote", name, d["out"].shape, "finite:", bool(np.isfinite(d["out"]).all()))
 
 
+def fixture_sched(name):
+    """NeRFRenderer.sched_step (reference nerf.py:324-344): sample-count schedule as the trainer drives it."""
+    from render import NeRFRenderer
+    sched = [[2, 4, 9], [32, 64, 96], [8, 16, 24]]
+    steps = [1, 1, 1, 2, 5, 1, 3]
+    ren = NeRFRenderer(n_coarse=16, n_fine=4, sched=sched)
+    rows = []
+    for st in steps:
+        ren.sched_step(st)
+        rows.append([ren.n_coarse, ren.n_fine, int(ren.iter_idx), int(ren.last_sched)])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), sched=np.array(sched), steps=np.array(steps), rows=np.array(rows))
+    print("wrote", name, rows)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_shims()
@@ -631,6 +645,7 @@ def main():
     fixture_encoder("encoder_nopool", seed=5, NS=1, H=48, W=32, use_first_pool=False)  # conf/exp/sn64.conf
     fixture_nerf_variants("nerf_variants")
     fixture_yolo_cull("yolo_cull")
+    fixture_sched("sched")
 
 
 if __name__ == "__main__":
