@@ -44,20 +44,29 @@ FOCAL, Z_NEAR, Z_FAR = 131.25, 0.8, 1.8
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 
 
+D_LATENT = 512  # 1792 with --workload c3
+
+
 def flop_per_ray(projected=False):
     """MLP GEMM FLOPs per ray: reference operation order, or with lin_z moved to the per-scene projection."""
-    per_vs = 42 * 512 + (0 if projected else 3 * 512 * 512) + 6 * 512 * 512
+    per_vs = 42 * 512 + (0 if projected else 3 * D_LATENT * 512) + 6 * 512 * 512
     post = 4 * 512 * 512 + 512 * 4
     per_sample = 2 * (NS * per_vs + post)
     return per_sample * (KC + (KC + KF))
 
 
-def describe():
+WORKLOADS = {
+    "c2": "C2: 128x128 render, 3 source views, ResNet34 encoder, 64 coarse + 32 fine (16 depth) samples, white bkgd",
+    "c3": "C3: 128x128 render, 3 source views, YOLO-sized conditioning (L=1792 latent at 16x16 supplied through "
+          "set_latent: the YOLOv7 backbone is outside the reference tree), 64 coarse + 32 fine (16 depth) samples",
+}
+
+
+def describe(workload="c2"):
     return {
         "metric": METRIC, "unit": "rays/s", "flop_per_ray": flop_per_ray(),
         "flop_per_ray_projected": flop_per_ray(True),
-        "config": {"workload": "C2: 128x128 render, 3 source views, ResNet34 encoder, 64 coarse + 32 fine "
-                               "(16 depth) samples, white bkgd", "rays_per_step_per_gpu": H * W},
+        "config": {"workload": WORKLOADS[workload], "rays_per_step_per_gpu": H * W},
     }
 
 
@@ -69,10 +78,14 @@ def main():
     ap.add_argument("--cpu-rays", type=int, default=1536, help="ray subset for the CPU baseline (0 = skip)")
     ap.add_argument("--projection", choices=["auto", "on", "off"], default="auto",
                     help="latent projection mode of the fused MLP (off = the reference's operation order)")
+    ap.add_argument("--workload", choices=["c2", "c3"], default="c2",
+                    help="c2 = BASELINE.json configs[1] (default, the bench line); c3 = configs[2], L=1792 conditioning")
     ap.add_argument("--describe", action="store_true", help="print the workload description and exit (no GPU)")
     args = ap.parse_args()
+    global D_LATENT
+    D_LATENT = 1792 if args.workload == "c3" else 512
     if args.describe:
-        print(json.dumps(describe()))
+        print(json.dumps(describe(args.workload)))
         return
 
     import numpy as np
@@ -100,11 +113,15 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     # ---- scene: weights, encoder, cameras
-    net = make_model(pconf.default_mv()["model"]).eval()
+    mconf = pconf.default_mv()
+    if args.workload == "c3":
+        mconf.d["model"]["encoder"]["backbone"] = "custom"   # d_latent = 1792 (reference custom_encoder.py:22)
+    net = make_model(mconf["model"]).eval()
     sd = {}
-    sd.update({"mlp_coarse." + k: v for k, v in synth.mlp_state(71).items()})
-    sd.update({"mlp_fine." + k: v for k, v in synth.mlp_state(72).items()})
-    sd.update(synth.resnet34_state(74))
+    sd.update({"mlp_coarse." + k: v for k, v in synth.mlp_state(71, d_latent=D_LATENT).items()})
+    sd.update({"mlp_fine." + k: v for k, v in synth.mlp_state(72, d_latent=D_LATENT).items()})
+    if args.workload == "c2":
+        sd.update(synth.resnet34_state(74))
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
     net = net.to(dev)
     net.set_latent_projection(args.projection)
@@ -114,8 +131,10 @@ def main():
     focal, c = torch.tensor(FOCAL), torch.tensor([[W * 0.5, H * 0.5]])
     poses = torch.from_numpy(src)[None]
 
+    lat_in = torch.from_numpy(synth.latent(76, NS, 1792, 16, 16)).to(dev) if args.workload == "c3" else None
+
     def encode():
-        net.encode(images[None], poses, focal, c=c)
+        net.encode(images[None], poses, focal, c=c, latent=lat_in)   # c3: the backbone's output is an input
 
     encode()
     torch.cuda.synchronize()
@@ -191,7 +210,7 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "mlp_traffic.json")) as fh:
             tj = json.load(fh)
-        if bool(tj.get("projected_latent")) == bool(projected):
+        if bool(tj.get("projected_latent")) == bool(projected) and args.workload == "c2":
             traffic, traffic_note = tj["bytes_per_launch"], "%s: %s" % (tj["tag"], tj["method"])
     except (OSError, ValueError, KeyError):
         pass
@@ -203,7 +222,7 @@ def main():
         "metric": METRIC, "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": dict(describe()["config"], n_views=NS, n_coarse=KC, n_fine=KF, n_fine_depth=KFD,
+        "config": dict(describe(args.workload)["config"], n_views=NS, n_coarse=KC, n_fine=KF, n_fine_depth=KFD,
                        global_rays_per_step=world * n_rays,
                        parallelism="rays sharded, 1 process/GPU, dp%d, 1 all-gather/frame" % world),
         "encode_ms": encode_ms, "projection_ms": projection_ms,
@@ -223,7 +242,8 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import pnyolo_oracle as orc  # CPU baseline leg: the oracle as the thing timed beside the GPU
         lat = net.latent(0).cpu().numpy()
-        sc = orc.Scene(synth.mlp_state(71), synth.mlp_state(72), lat, src, focal, c, W, H)
+        sc = orc.Scene(synth.mlp_state(71, d_latent=D_LATENT), synth.mlp_state(72, d_latent=D_LATENT), lat, src, focal, c,
+                       W, H)
         nb = args.cpu_rays
         rs = np.random.RandomState(0)
         sub = rays[0, torch.from_numpy(rs.choice(n_rays, nb, replace=False)).to(dev)].cpu()
@@ -235,7 +255,7 @@ def main():
         orc.render(sc, sub, KC, KF, KFD, *draws, chunk=50000)
         cpu_s = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": nb / cpu_s, "unit": "rays/s", "cores": torch.get_num_threads(),
-                               "kind": "port", "sample": "%d random rays of the same C2 frame, %.1f s" % (nb, cpu_s)}
+                               "kind": "port", "sample": "%d random rays of the same %s frame, %.1f s" % (nb, args.workload.upper(), cpu_s)}
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
