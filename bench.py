@@ -121,7 +121,7 @@ def main():
     sd.update({"mlp_coarse." + k: v for k, v in synth.mlp_state(71, d_latent=D_LATENT).items()})
     sd.update({"mlp_fine." + k: v for k, v in synth.mlp_state(72, d_latent=D_LATENT).items()})
     if args.workload == "c2":
-        sd.update(synth.resnet34_state(74))
+        sd.update(synth.resnet34_state(74, residual_gain=0.25))   # latent O(1), like a trained trunk
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
     net = net.to(dev)
     net.set_latent_projection(args.projection)
@@ -252,10 +252,21 @@ def main():
         # the box's CPU share for one GPU is 16 cores (more threads only oversubscribe the small GEMMs)
         torch.set_num_threads(min(os.cpu_count() or 1, 16))
         t0 = time.perf_counter()
-        orc.render(sc, sub, KC, KF, KFD, *draws, chunk=50000)
+        cpu_out = orc.render(sc, sub, KC, KF, KFD, *draws, chunk=50000)
         cpu_s = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": nb / cpu_s, "unit": "rays/s", "cores": torch.get_num_threads(),
                                "kind": "port", "sample": "%d random rays of the same %s frame, %.1f s" % (nb, args.workload.upper(), cpu_s)}
+        # the same rays and draws through the HIP path: the checker's output beside the product's (not timed)
+        ren.draws = dict(u_coarse=draws[0], u_fine=draws[1], u_fine2=draws[2], g_depth=draws[3])
+        with torch.no_grad():
+            gpu_out = ren(net, sub[None].to(dev))
+        ec = (gpu_out["coarse"]["rgb"][0].cpu() - cpu_out["coarse"]["rgb"]).abs().max(dim=1)[0]
+        ef = (gpu_out["fine"]["rgb"][0].cpu() - cpu_out["fine"]["rgb"]).abs().max(dim=1)[0]
+        out["parity"] = {"rays": nb, "tolerance": 1e-4, "coarse_rgb_max_abs_err": float(ec.max()),
+                         "fine_rgb_median_abs_err": float(ef.median()),
+                         "fine_rays_over_tolerance": int((ef > 1e-4).sum()),
+                         "note": "fine rays over tolerance are importance-sampling bin flips (discontinuous in the "
+                                 "coarse weights, DESIGN.md section 2)"}
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

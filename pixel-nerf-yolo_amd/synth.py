@@ -80,10 +80,13 @@ def scene_cameras(ns, radius=1.3, phi=-20.0):
     return src, tgt
 
 
-def resnet34_state(seed, prefix="encoder.model."):
+def resnet34_state(seed, prefix="encoder.model.", residual_gain=1.0):
     """Random ResNet-34 trunk parameters with the torchvision key names the reference
     checkpoint uses: conv1, bn1, layer1..layer3 (layer4/fc are unused by
-    SpatialEncoder with num_layers=4, reference src/model/encoder.py:139-157)."""
+    SpatialEncoder with num_layers=4, reference src/model/encoder.py:139-157).
+    residual_gain scales every block's last batch-norm weight: eval-mode batch norm with random
+    running statistics does not normalise, so with gain 1 the residual stream doubles in variance per
+    block and the latent comes out O(100); 0.25 keeps it O(1) like a trained trunk's."""
     rs = np.random.RandomState(seed)
     sd = {}
 
@@ -107,6 +110,8 @@ def resnet34_state(seed, prefix="encoder.model."):
             bn(p + "bn1", cout)
             conv(p + "conv2", cout, cout, 3)
             bn(p + "bn2", cout)
+            if residual_gain != 1.0:
+                sd[prefix + p + "bn2.weight"] = (sd[prefix + p + "bn2.weight"] * residual_gain).astype(np.float32)
             if b == 0 and (cin != cout):
                 conv(p + "downsample.0", cout, cin, 1)
                 bn(p + "downsample.1", cout)
