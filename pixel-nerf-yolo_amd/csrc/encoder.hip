@@ -30,27 +30,31 @@ struct ConvArgs {
     long long npix;
 };
 
-// SPLIT = 1: 4 waves per workgroup, one 64x64 output tile each.
+// Output tile of a wave: (32*NT output channels) x (32*MT pixels), NT, MT in {1, 2}.
+// SPLIT = 1: 4 waves per workgroup, one output tile each.
 // SPLIT = 8: 8 waves per workgroup share ONE output tile, wave w takes k-iterations j = w (mod 8); the
-//            partial accumulators are reduced through LDS (8 x 16 KiB) and wave w finishes registers
-//            [8w, 8w+8) of every tile position.  Used for the deep, spatially small layers, where a
-//            tile per wave leaves 3-12 workgroups on the chip running up to 288 dependent iterations.
-template <int SPLIT>
+//            partial accumulators are reduced through LDS and wave w finishes 1/8 of the (position, register)
+//            pairs.  Used for the deep, spatially small layers, where a tile per wave leaves a handful of
+//            workgroups on the chip running up to 288 dependent iterations.
+// The host picks 32x32 tiles (NT = MT = 1) whenever 64x64 tiles would not give every CU a workgroup: the
+// ResNet-34 trunk at 128x128 input has 192 .. 3072 output pixels per layer, i.e. 12 .. 48 tiles of 64x64.
+template <int SPLIT, int NT, int MT>
 __global__ __launch_bounds__(SPLIT == 1 ? 256 : 512) void conv_mfma_kernel(const ConvArgs a) {
+    constexpr int TN = 32 * NT, TMp = 32 * MT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m0 = lane & 31, hh = lane >> 5;
-    const int tiles_n = a.cout / 64;
+    const int tiles_n = a.cout / TN;
     const long long tile = SPLIT == 1 ? (long long)blockIdx.x * 4 + wave : (long long)blockIdx.x;
     const long long tile_m = tile / tiles_n;
     const int tile_n = (int)(tile - tile_m * tiles_n);
-    if (tile_m * 64 >= a.npix) return;
+    if (tile_m * TMp >= a.npix) return;
 
-    long long pix[2];
-    int iy0[2], ix0[2], img[2];
-    bool valid[2];
+    long long pix[MT];
+    int iy0[MT], ix0[MT], img[MT];
+    bool valid[MT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        long long p = tile_m * 64 + 32 * mt + m0;
+    for (int mt = 0; mt < MT; ++mt) {
+        long long p = tile_m * TMp + 32 * mt + m0;
         valid[mt] = p < a.npix;
         if (!valid[mt]) p = a.npix - 1;
         pix[mt] = p;
@@ -61,31 +65,30 @@ __global__ __launch_bounds__(SPLIT == 1 ? 256 : 512) void conv_mfma_kernel(const
         iy0[mt] = oy * a.stride - a.pad;
         ix0[mt] = ox * a.stride - a.pad;
     }
-    f32x16 acc[2][2];
+    f32x16 acc[NT][MT];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.f;
 
-    const float4* w0 = reinterpret_cast<const float4*>(a.w) + (size_t)(2 * tile_n) * a.J * 64 + lane;
-    const float4* w1 = w0 + (size_t)a.J * 64;
+    const float4* w0 = reinterpret_cast<const float4*>(a.w) + (size_t)(NT * tile_n) * a.J * 64 + lane;
     const int ntap = a.k * a.k;
-    // One k-iteration's operands: 2 weight fragments (packed, coalesced) and 2 patch fragments
+    // One k-iteration's operands: NT weight fragments (packed, coalesced) and MT patch fragments
     // (4 consecutive input channels of one tap per lane; zero outside the image / beyond K).
     struct Frag {
-        float4 a0, a1, b[2];
+        float4 a[NT], b[MT];
     };
     auto fetch = [&](int j, Frag& f) {
         const int jj = j < a.J ? j : a.J - 1;  // clamped prefetch past the end (discarded)
         const int k0 = 8 * jj + 4 * hh;
         const int tap = k0 / a.cin_p, ci = k0 - tap * a.cin_p;
         const int ky = tap / a.k, kx = tap - ky * a.k;
-        f.a0 = w0[(size_t)jj * 64];
-        f.a1 = w1[(size_t)jj * 64];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int nt = 0; nt < NT; ++nt) f.a[nt] = w0[((size_t)nt * a.J + jj) * 64];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
             const int iy = iy0[mt] + ky, ix = ix0[mt] + kx;
             const bool ok = valid[mt] && tap < ntap && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
             f.b[mt] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -93,11 +96,10 @@ __global__ __launch_bounds__(SPLIT == 1 ? 256 : 512) void conv_mfma_kernel(const
         }
     };
     auto mac = [&](const Frag& f) {
-#define PNY_STEP(c)                                                                             \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0.c, f.b[0].c, acc[0][0], 0, 0, 0);     \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0.c, f.b[1].c, acc[0][1], 0, 0, 0);     \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1.c, f.b[0].c, acc[1][0], 0, 0, 0);     \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1.c, f.b[1].c, acc[1][1], 0, 0, 0);
+#define PNY_STEP(c)                                                                         \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                       \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                   \
+            acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[nt].c, f.b[mt].c, acc[nt][mt], 0, 0, 0);
         PNY_STEP(x)
         PNY_STEP(y)
         PNY_STEP(z)
@@ -131,24 +133,26 @@ __global__ __launch_bounds__(SPLIT == 1 ? 256 : 512) void conv_mfma_kernel(const
     }
     if (SPLIT > 1) {
         // reduce the SPLIT partial tiles: part[wave][tile position (nt,mt)][reg][lane]
+        constexpr int NPOS = NT * MT, PAIRS = NPOS * 16, PER = PAIRS / SPLIT;
+        static_assert(PAIRS % SPLIT == 0, "pairs per wave");
         extern __shared__ float part[];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) part[((wave * 4 + nt * 2 + mt) * 16 + r) * 64 + lane] = acc[nt][mt][r];
+                for (int r = 0; r < 16; ++r) part[((wave * NPOS + nt * MT + mt) * 16 + r) * 64 + lane] = acc[nt][mt][r];
         __syncthreads();
-        // each wave finishes 8 of the 64 (position, reg) pairs: pairs p = 8*wave .. 8*wave+7
+        // each wave finishes PER of the PAIRS (position, reg) pairs: pairs p = PER*wave .. PER*wave + PER - 1
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int pr = 8 * wave + i;  // = (nt*2+mt)*16 + r
+        for (int i = 0; i < PER; ++i) {
+            const int pr = PER * wave + i;  // = (nt*MT+mt)*16 + r
             float sum = 0.f;
 #pragma unroll
-            for (int w = 0; w < SPLIT; ++w) sum += part[((w * 4) * 16 + pr) * 64 + lane];
-            const int pos = pr >> 4, r = pr & 15, nt = pos >> 1, mt = pos & 1;
+            for (int w = 0; w < SPLIT; ++w) sum += part[((w * NPOS) * 16 + pr) * 64 + lane];
+            const int pos = pr >> 4, r = pr & 15, nt = pos / MT, mt = pos - nt * MT;
             if (!valid[mt]) continue;
-            const int c = 64 * tile_n + 32 * nt + 8 * (r >> 2) + 4 * hh + (r & 3);
+            const int c = TN * tile_n + 32 * nt + 8 * (r >> 2) + 4 * hh + (r & 3);
             float v = sum * a.scale[c] + a.shift[c];
             const size_t o = (size_t)pix[mt] * a.cout + c;
             if (a.resid) v += a.resid[o];
@@ -158,13 +162,13 @@ __global__ __launch_bounds__(SPLIT == 1 ? 256 : 512) void conv_mfma_kernel(const
         return;
     }
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
         if (!valid[mt]) continue;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int c = 64 * tile_n + 32 * nt + 8 * q + 4 * hh;
+                const int c = TN * tile_n + 32 * nt + 8 * q + 4 * hh;
                 const float4 sc = *reinterpret_cast<const float4*>(a.scale + c);
                 const float4 sh = *reinterpret_cast<const float4*>(a.shift + c);
                 float4 v;
@@ -432,22 +436,36 @@ static bool run_conv(const ConvLayer& L, const float* in, int n, int hin, int wi
     a.J = L.J;
     a.relu = relu;
     a.npix = (long long)n * a.hout * a.wout;
-    const long long tiles = ((a.npix + 63) / 64) * (L.cout / 64);
-    // split K inside the workgroup when there are few tiles and a long reduction
-    if (L.J >= 32 && tiles <= 512) {
-        constexpr int lds = 8 * 4 * 16 * 64 * (int)sizeof(float);  // 128 KiB
-        static bool attr_set[64] = {};  // per device: function attributes are per device
-        int dev_ = 0;
-        (void)hipGetDevice(&dev_);
-        dev_ &= 63;
-        if (!attr_set[dev_]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<8>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            attr_set[dev_] = true;
-        }
-        hipLaunchKernelGGL(conv_mfma_kernel<8>, dim3((unsigned)tiles), dim3(512), lds, st, a);
+    // tile shape: 64x64 per wave where that still gives every CU work, else 32x32 (4x the tiles, 1/4 of the
+    // dependent MFMA chain per wave); the K split inside the workgroup for long reductions over few tiles
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
+    const long long tiles64 = ((a.npix + 63) / 64) * (L.cout / 64);
+    const long long tiles32 = ((a.npix + 31) / 32) * (L.cout / 32);
+    const bool small = tiles64 < 2 * (long long)cus;
+    const long long tiles = small ? tiles32 : tiles64;
+    const bool split = L.J >= 32 && tiles <= 4 * (long long)cus;
+    static bool attr_set[64] = {};  // per device: function attributes are per device
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    dev_ &= 63;
+    if (!attr_set[dev_]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<8, 2, 2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4 * 16 * 64 * (int)sizeof(float));
+        attr_set[dev_] = true;
+    }
+    if (split && small) {
+        hipLaunchKernelGGL((conv_mfma_kernel<8, 1, 1>), dim3((unsigned)tiles), dim3(512), 8 * 1 * 16 * 64 * sizeof(float), st, a);
+    } else if (split) {
+        hipLaunchKernelGGL((conv_mfma_kernel<8, 2, 2>), dim3((unsigned)tiles), dim3(512), 8 * 4 * 16 * 64 * sizeof(float), st, a);
+    } else if (small) {
+        hipLaunchKernelGGL((conv_mfma_kernel<1, 1, 1>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, a);
     } else {
-        hipLaunchKernelGGL(conv_mfma_kernel<1>, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((conv_mfma_kernel<1, 2, 2>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, a);
     }
     return hipGetLastError() == hipSuccess;
 }
