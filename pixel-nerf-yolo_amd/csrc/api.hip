@@ -390,6 +390,7 @@ int pny_scene_encode(pny_scene* s, const float* images_dev, int ns, int height, 
     PNY_HIP(hipSetDevice(s->m->desc.device));
     int hl = 0, wl = 0;
     encoder_latent_size(height, width, &hl, &wl);
+    if ((long long)hl * wl * 512 >= (1ll << 31)) return fail(PNY_ERR_ARG, "pny_scene_encode: latent too large for 32-bit tap offsets");
     int rc;
     if ((rc = s->latent.reserve((size_t)ns * 512 * hl * wl * sizeof(float)))) return rc;
     const bool pool = s->m->desc.enc_use_first_pool != 0;
