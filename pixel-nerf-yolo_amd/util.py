@@ -1,7 +1,7 @@
 """
 Ray generation and the YOLO detection tail with the reference's signatures (src/util/util.py:240-278 ``gen_rays``,
-:808-876 ``gen_rays_yolo``), executed by libpnyolo's gen_rays kernel.  Output lives on the
-device of ``poses`` (which must be a CUDA device: there is no CPU path).
+:808-876 ``gen_rays_yolo``), executed by libpnyolo's gen_rays kernel.  Output lives on a CUDA
+device (that of ``poses``, or the current one when ``poses`` is a CPU tensor as at the reference's call sites).
 """
 import ctypes as C
 
@@ -20,9 +20,19 @@ def _pair(v, name):
 
 
 def _device_of(poses, device):
-    dev = torch.device(device) if device is not None else poses.device
+    """Device the rays are generated on: `device` if given, the device of `poses` if that is a GPU, else the
+    current CUDA device -- the reference's call sites pass CPU poses and move the result afterwards
+    (eval/eval.py:258 `.to(device=device)`, a no-op then).  No GPU at all is an error: there is no CPU path."""
+    if device is not None:
+        dev = torch.device(device)
+    elif poses.device.type == "cuda":
+        dev = poses.device
+    elif torch.cuda.is_available():
+        dev = torch.device("cuda", torch.cuda.current_device())
+    else:
+        dev = poses.device
     if dev.type != "cuda":
-        raise RuntimeError("gen_rays (libpnyolo) needs a cuda device: pass poses on the GPU or device=")
+        raise RuntimeError("gen_rays (libpnyolo) needs a cuda device: there is no CPU path")
     return dev
 
 

@@ -64,6 +64,15 @@ def render_debug(ren, net, rays, draws, kc, kt):
 
 
 # --------------------------------------------------------------------------- golden: rays
+def test_gen_rays_accepts_cpu_poses_like_the_call_sites(golden):
+    """eval/eval.py:247-258 of the reference: gen_rays(poses_cpu, ...).to(device=device)."""
+    g = golden("rays")
+    pose = torch.from_numpy(synth.pose_spherical(30.0, -20.0, 1.3))[None]
+    a = gen_rays(pose, 16, 12, torch.tensor(20.0), 0.8, 1.8).to(device=DEV)
+    b = gen_rays(pose.to(DEV), 16, 12, torch.tensor(20.0), 0.8, 1.8)
+    assert a.is_cuda and torch.equal(a, b)
+
+
 def test_gen_rays_golden(golden):
     g = golden("rays")
     poses = dt(g["poses"])
