@@ -651,6 +651,74 @@ def test_yolo_latent_culling_golden(golden, projection):
     assert maxabs(out, g["out"]) < TOL * max(1.0, float(np.abs(g["out"]).max()))
 
 
+@pytest.mark.parametrize("coarse_flag", [False, True])
+def test_eval_call_site_flow(tmp_path, coarse_flag):
+    """The call sequence of the reference's eval/eval.py:135-150,236-285, argument for argument, on this package:
+    a `pixel_nerf_latest` checkpoint written in the reference's format, CPU poses into gen_rays, GPU focal into
+    encode, ray batches through the bound renderer."""
+    import os
+    from types import SimpleNamespace
+    device = torch.device(DEV)
+    conf = pconf.default_mv()
+    args = SimpleNamespace(checkpoints_path=str(tmp_path), name="exp", resume=True, coarse=coarse_flag, gpu_id=[0],
+                           ray_batch_size=3000, scale=1.0, include_src=False)
+    # the checkpoint a reference training run leaves behind: torch.save(net.state_dict()) (models.py:368)
+    ref_like = make_model(conf["model"])
+    sd = {}
+    sd.update({"mlp_coarse." + k: torch.from_numpy(v) for k, v in synth.mlp_state(71).items()})
+    sd.update({"mlp_fine." + k: torch.from_numpy(v) for k, v in synth.mlp_state(72).items()})
+    sd.update({k: torch.from_numpy(v) for k, v in synth.resnet34_state(74, residual_gain=0.25).items()})
+    ref_like.load_state_dict(sd, strict=False)
+    os.makedirs(os.path.join(args.checkpoints_path, args.name))
+    torch.save(ref_like.state_dict(), os.path.join(args.checkpoints_path, args.name, "pixel_nerf_latest"))
+
+    net = make_model(conf["model"]).to(device=device).load_weights(args)
+    renderer = NeRFRenderer.from_conf(conf["renderer"], lindisp=False, eval_batch_size=args.ray_batch_size).to(device=device)
+    if args.coarse:
+        net.mlp_fine = None
+    if renderer.n_coarse < 64:
+        renderer.n_coarse = 64
+    if args.coarse:
+        renderer.n_coarse = 64
+        renderer.n_fine = 128
+        renderer.using_fine = True
+    render_par = renderer.bind_parallel(net, args.gpu_id, simple_output=True).eval()
+
+    NV, H, W, z_near, z_far = 5, 64, 64, 0.8, 1.8
+    images = torch.from_numpy(synth.images(5, NV, H, W))                          # (NV, 3, H, W), CPU
+    poses = torch.from_numpy(np.stack([synth.pose_spherical(30.0 * i, -20.0, 1.3) for i in range(NV)]))
+    focal, c = torch.tensor(65.6), None
+    src_view_mask = torch.tensor([True, False, True, False, False])
+    src_poses = poses[src_view_mask].to(device=device)
+    target = ~src_view_mask
+    n_gen_views = int(target.sum())
+    all_rays = gen_rays(poses[target].reshape(-1, 4, 4), W, H, focal * args.scale, z_near, z_far,
+                        c=c * args.scale if c is not None else None).reshape(-1, 8).to(device=device)
+    focal = focal.to(device=device)
+    rays_spl = torch.split(all_rays, args.ray_batch_size, dim=0)
+    net.encode(images[src_view_mask].to(device=device).unsqueeze(0), src_poses.unsqueeze(0), focal, c=c)
+    all_rgb, all_depth = [], []
+    for rays in rays_spl:
+        rgb, depth = render_par(rays[None])
+        all_rgb.append(rgb[0].cpu())
+        all_depth.append(depth[0].cpu())
+    all_rgb, all_depth = torch.cat(all_rgb, dim=0), torch.cat(all_depth, dim=0)
+    assert all_rgb.shape == (n_gen_views * H * W, 3) and all_depth.shape == (n_gen_views * H * W,)
+    img = torch.clamp(all_rgb.reshape(n_gen_views, H, W, 3), 0.0, 1.0).numpy()
+    assert np.isfinite(img).all() and float(all_rgb.min()) >= -1e-5 and float(all_rgb.max()) <= 1.0 + 1e-4
+    assert float(all_depth.min()) >= 0.0 and float(all_depth.max()) <= z_far + 1e-4
+    assert float(img.std()) > 1e-3                                                 # an image, not a constant
+    # the loaded weights are the checkpoint's: one model probe against the oracle
+    scene = orc.Scene(synth.mlp_state(71), synth.mlp_state(72), net.latent(0).cpu().numpy(), src_poses.cpu().numpy(),
+                      np.float32(65.6), None, W, H)
+    rs = np.random.RandomState(1)
+    xyz = rs.uniform(-0.4, 0.4, size=(50, 3)).astype(np.float32)
+    vd = rs.standard_normal((50, 3)).astype(np.float32)
+    with torch.no_grad():
+        got = net(dt(xyz)[None], coarse=False, viewdirs=dt(vd)[None])[0]
+    assert maxabs(got, orc.query(scene, xyz, vd, coarse=args.coarse)) < TOL  # --coarse: the fine pass runs on mlp_coarse
+
+
 def test_misaligned_rays_are_refused(golden):
     """The fused kernel reads a ray row as two 16-byte words: an unaligned pointer is an argument error,
     not a fault."""
