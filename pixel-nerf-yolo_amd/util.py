@@ -32,7 +32,7 @@ def _device_of(poses, device):
     else:
         dev = poses.device
     if dev.type != "cuda":
-        raise RuntimeError("gen_rays (libpnyolo) needs a cuda device: there is no CPU path")
+        raise RuntimeError("libpnyolo needs a cuda device: there is no CPU path")
     return dev
 
 
@@ -78,11 +78,9 @@ def convert_cells_to_bboxes(predictions, anchors, h, w, is_predictions=True, as_
     """reference src/util/util.py:633-689.  predictions (B, h, w, A, 7 | 6) on a cuda device.
     Returns the reference's nested list (B x (A*h*w) x 6: [class, score, x, y, w, h]) or, with
     as_tensor=True, a (B, A*h*w, 6) device tensor (no host round trip)."""
-    dev = predictions.device
-    if dev.type != "cuda":
-        raise RuntimeError("convert_cells_to_bboxes (libpnyolo) needs the cell grid on a cuda device")
+    dev = _device_of(predictions, None)   # the reference's call site hands over CPU tensors (YoloTrainer.py:279-289)
     L = _lib.load()
-    p = predictions.detach().to(torch.float32).contiguous()
+    p = predictions.detach().to(dev, torch.float32).contiguous()
     B, A = p.shape[0], p.shape[3]
     assert p.shape[1] == h and p.shape[2] == w and p.shape[4] == (7 if is_predictions else 6)
     anc = torch.as_tensor(anchors, dtype=torch.float32).detach().cpu().reshape(-1, 2).contiguous()
