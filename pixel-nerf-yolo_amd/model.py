@@ -35,6 +35,19 @@ class _ResnetBlockFC(nn.Module):
         nn.init.zeros_(self.fc_1.weight)
 
 
+# Bumped by every parameter / buffer / submodule registration in the process (see PixelNeRFNet._weights_key).
+_STRUCT_EPOCH = [0]
+
+
+def _bump_struct_epoch(*_args, **_kwargs):
+    _STRUCT_EPOCH[0] += 1
+
+
+for _reg in ("register_module_parameter_registration_hook", "register_module_buffer_registration_hook",
+             "register_module_module_registration_hook"):
+    getattr(torch.nn.modules.module, _reg)(_bump_struct_epoch)
+
+
 class ResnetFC(nn.Module):
     """Parameter container with the reference's names / shapes / init
     (src/model/resnetfc.py:66-132, from_conf :188-205).  The arithmetic lives in csrc/mlp.hip."""
@@ -246,8 +259,15 @@ class PixelNeRFNet(nn.Module):
             pass
 
     def _weights_key(self):
-        ps = list(self.state_dict(keep_vars=True).items())
-        return tuple((k, v.data_ptr(), v._version) for k, v in ps)
+        """Identity of every parameter / buffer value: (storage pointer, in-place version counter).  Building the
+        state_dict costs ~170 us per call, so the tensor list is cached and rebuilt only after a structural change
+        anywhere (a parameter, buffer or submodule registered or replaced: PyTorch's global registration hooks bump
+        _STRUCT_EPOCH) or when the fine MLP is attached / detached."""
+        sig = (_STRUCT_EPOCH[0], id(self.mlp_fine))
+        if sig != getattr(self, "_tracked_sig", None):
+            self._tracked = list(self.state_dict(keep_vars=True).items())
+            self._tracked_sig = sig
+        return tuple((k, v.data_ptr(), v._version) for k, v in self._tracked)
 
     def _sync(self):
         """Create the native model on first use; re-upload weights when parameters changed

@@ -123,6 +123,33 @@ def test_renderer_interface_and_sched():
     ren.n_coarse, ren.n_fine, ren.using_fine = 128, 0, False
 
 
+def test_weight_change_detection():
+    """PixelNeRFNet._weights_key must change for every way the weights can change (the native copy is re-uploaded
+    when it does): in-place updates, load_state_dict, .data assignment, a replaced Parameter, a replaced submodule,
+    the fine MLP detached."""
+    net = make_model(pconf.default_mv()["model"]).eval()
+    k0 = net._weights_key()
+    assert net._weights_key() == k0
+    with torch.no_grad():
+        net.mlp_coarse.lin_in.bias.add_(1.0)                       # optimizer-style in-place update
+    k1 = net._weights_key()
+    assert k1 != k0
+    net.load_state_dict(net.state_dict())                          # in-place copy
+    k2 = net._weights_key()
+    assert k2 != k1
+    net.mlp_fine.lin_out.weight.data = torch.zeros_like(net.mlp_fine.lin_out.weight)
+    k3 = net._weights_key()
+    assert k3 != k2
+    net.mlp_coarse.blocks[0].fc_0.weight = torch.nn.Parameter(torch.zeros(512, 512))   # a new Parameter object
+    k4 = net._weights_key()
+    assert k4 != k3
+    net.mlp_coarse.blocks[1] = type(net.mlp_coarse.blocks[1])(512)                      # a new submodule
+    k5 = net._weights_key()
+    assert k5 != k4
+    net.mlp_fine = None
+    assert net._weights_key() != k5
+
+
 def test_sched_step_matches_reference(golden):
     """tests/golden/sched.npz: the reference's NeRFRenderer driven through the same step sequence."""
     g = golden("sched")
