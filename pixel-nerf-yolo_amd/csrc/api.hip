@@ -673,7 +673,7 @@ int pny_sample_fine(const float* rays_dev, const float* z_coarse_dev, const floa
         return fail(PNY_ERR_ARG, "pny_sample_fine: bad sample counts");
     if (n > 0 && (!rays_dev || !z_coarse_dev || !weights_dev || !z_out_dev || (n_fine_depth > 0 && !depth_dev)))
         return fail(PNY_ERR_ARG, "pny_sample_fine: null argument");
-    if ((size_t)(2 * n_coarse + 1 + n_fine) * 64 * sizeof(float) > 160 * 1024)
+    if ((size_t)(4 * n_coarse + 1 + 2 * n_fine) * 4 * sizeof(float) > 160 * 1024)
         return fail(PNY_ERR_ARG, "pny_sample_fine: n_coarse + n_fine too large for the LDS-resident sort");
     launch_sample_fine(rays_dev, z_coarse_dev, weights_dev, depth_dev, n, n_coarse, n_fine, n_fine_depth, depth_std,
                        lindisp, u_dev, u2_dev, g_dev, seed, z_out_dev, (hipStream_t)stream);
@@ -731,7 +731,7 @@ int pny_render(pny_scene* s, const float* rays_dev, int64_t n, const pny_render_
     if (o->n_fine > 0) {
         float* zf = out->z_fine ? out->z_fine : W + o_zf;
         float* sf = out->sample_fine ? out->sample_fine : W + o_sf;
-        if ((size_t)(2 * kc + 1 + o->n_fine) * 64 * sizeof(float) > 160 * 1024)
+        if ((size_t)(4 * kc + 1 + 2 * o->n_fine) * 4 * sizeof(float) > 160 * 1024)
             return fail(PNY_ERR_ARG, "pny_render: n_coarse + n_fine too large for the LDS-resident sort");
         launch_sample_fine(rays_dev, zc, wc, dc, n, kc, o->n_fine, o->n_fine_depth, o->depth_std, o->lindisp,
                            o->u_fine_dev, o->u_fine2_dev, o->g_depth_dev, o->seed, zf, st);
