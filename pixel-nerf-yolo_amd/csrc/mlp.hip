@@ -889,10 +889,9 @@ int mlp_cu_count() {
     return cus;
 }
 
-// Kernel shape per launch.  PNYOLO_MLP_VARIANT forces "8x64", "16x64" or "8x32" (see Cfg); otherwise
-// 8x64 (fastest in steady state), except for launches too small to give every CU a 64-sample tile:
-// with at most half as many 64-sample tiles as CUs (training / visualisation batches, one YOLO view)
-// the 32-sample shape spreads the same work over twice as many CUs and the launch takes about half as long.
+// Kernel shape per launch.  PNYOLO_MLP_VARIANT forces "8x64", "16x64" or "8x32" (see Cfg); otherwise 8x64
+// (fastest in steady state) unless the 32-sample shape finishes the launch sooner: launches that cannot give
+// every CU a 64-sample tile (training / visualisation batches) or that end in a mostly empty last round.
 static int forced_variant() {
     static int v = -2;
     if (v == -2) {
@@ -907,8 +906,14 @@ static int forced_variant() {
 int mlp_pick_variant(long long n_points) {
     const int f = forced_variant();
     if (f >= 0) return f;
-    const long long tiles64 = (n_points + 63) / 64;
-    return (2 * tiles64 <= mlp_cu_count()) ? MLP_8x32 : MLP_8x64;
+    // estimated duration in units of one 64-sample tile on a CU of its own (measured: a lone 32-sample tile 0.55,
+    // two 32-sample workgroups sharing a CU 1.05 -- the steady-state handicap of the 8x32 shape)
+    const long long cus = mlp_cu_count();
+    const long long n64 = (n_points + 63) / 64, n32 = (n_points + 31) / 32;
+    const double t64 = (double)((n64 + cus - 1) / cus);
+    const long long full = n32 / (2 * cus), rem = n32 % (2 * cus);
+    const double t32 = 1.05 * (double)full + (rem == 0 ? 0.0 : (rem <= cus ? 0.55 : 1.05));
+    return t32 < t64 ? MLP_8x32 : MLP_8x64;
 }
 int mlp_tile_samples(int variant) { return variant == MLP_8x32 ? 32 : 64; }
 int mlp_max_grid(int variant) { return mlp_cu_count() * (variant == MLP_8x32 ? 2 : 1); }
