@@ -764,6 +764,29 @@ def test_yolo_metric_call_site_flow(golden):
     assert 0.0 <= precision <= 1.0 and 0.0 <= recall <= 1.0 and 0.0 <= f1 <= 1.0
 
 
+def test_mlp_shapes_golden(golden, projection):
+    """Reference goldens for other ResnetFC shapes: combine_layer = 0 (mean right after lin_in: no per-view block, the
+    kernel's degenerate slab path, nothing to project), combine_layer = 1 of 4 blocks, one block without a combine."""
+    g = golden("mlp_shapes")
+    seed, H, W = int(g["seed"]), int(g["H"]), int(g["W"])
+    for tag in "abc":
+        nb, cl, ns = (int(v) for v in g[tag + "_cfg"])
+        c = pconf.default_mv()
+        c.d["model"]["mlp_coarse"] = {"type": "resnet", "n_blocks": nb, "d_hidden": 512, "d_out": 4, "combine_layer": cl}
+        c.d["model"]["mlp_fine"] = {"type": "empty"}
+        net = make_model(c["model"]).eval()
+        sd = synth.mlp_state(seed * 10 + ord(tag), n_blocks=nb, combine_layer=cl)
+        net.mlp_coarse.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        net = net.to(DEV)
+        lat = torch.from_numpy(synth.latent(seed * 10 + 3, ns, 512, H // 2, W // 2))
+        net.encode(torch.zeros(1, ns, 3, H, W), torch.from_numpy(g[tag + "_poses"])[None], torch.tensor(33.0), latent=lat)
+        net.set_latent_projection(projection)
+        with torch.no_grad():
+            out = net(dt(g["xyz"])[None], coarse=True, viewdirs=dt(g["viewdirs"])[None])[0]
+        assert maxabs(out, g[tag + "_out"]) < TOL, tag
+        assert net.last_mlp_stats(full=True)["projected"] == (projection == "on" and min(cl, nb) > 0), tag
+
+
 def test_misaligned_rays_are_refused(golden):
     """The fused kernel reads a ray row as two 16-byte words: an unaligned pointer is an argument error,
     not a fault."""

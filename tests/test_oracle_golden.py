@@ -216,3 +216,18 @@ def test_yolo_latent_culling(golden):
     assert bool(torch.isfinite(out).all())
     scale = float(np.abs(g["out"]).max())
     assert maxabs(out, g["out"]) < 2e-6 * max(1.0, scale)
+
+
+def test_mlp_shapes(golden):
+    """combine_layer = 0 / 1 / none with 2 / 4 / 1 blocks: the oracle against the reference's model probes."""
+    from pixel_nerf_yolo_amd import synth
+    g = golden("mlp_shapes")
+    seed, H, W = int(g["seed"]), int(g["H"]), int(g["W"])
+    for tag in "abc":
+        nb, cl, ns = (int(v) for v in g[tag + "_cfg"])
+        lat = synth.latent(seed * 10 + 3, ns, 512, H // 2, W // 2)
+        sc = orc.Scene(synth.mlp_state(seed * 10 + ord(tag), n_blocks=nb, combine_layer=cl), None, lat, g[tag + "_poses"],
+                       np.float32(33.0), None, W, H, n_blocks=nb, combine_layer=cl)
+        out = orc.query(sc, g["xyz"], g["viewdirs"], coarse=True)
+        assert maxabs(out[:, :3], g[tag + "_out"][:, :3]) < 2e-6, tag
+        assert maxabs(out[:, 3], g[tag + "_out"][:, 3]) < 2e-5, tag

@@ -631,6 +631,45 @@ def fixture_sched(name):
     print("wrote", name, rows)
 
 
+def fixture_mlp_shapes(name, seed=17):
+    """ResnetFC shapes the standard fixtures do not cover (resnetfc.py:134-186 with other conf values): combine_layer = 0
+    (the cross-view mean directly after lin_in, no lin_z at all), combine_layer = 1 with 4 blocks, and a single block
+    with combine_layer = 1000 on one view.  Model probes only."""
+    from model import make_model
+
+    torch.manual_seed(seed)
+    H = W = 32
+    d = {"H": H, "W": W, "seed": seed}
+    rs = np.random.RandomState(seed)
+    pts = rs.uniform(-0.5, 0.5, size=(1, 70, 3)).astype(np.float32)
+    vd = rs.standard_normal((1, 70, 3)).astype(np.float32)
+    d["xyz"], d["viewdirs"] = pts[0], vd[0]
+    for tag, (nb, cl, ns) in {"a": (2, 0, 2), "b": (4, 1, 3), "c": (1, 1000, 1)}.items():
+        net = make_model(model_conf(n_blocks=nb, combine_layer=cl, has_fine=False)).eval()
+        sd = synth.mlp_state(seed * 10 + ord(tag), n_blocks=nb, combine_layer=cl)
+        net.mlp_coarse.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        lat = synth.latent(seed * 10 + 3, ns, 512, H // 2, W // 2)
+        enc = net.encoder
+
+        def fake_forward(x, enc=enc, lat=lat):
+            enc.latent = torch.from_numpy(lat)
+            enc.latent_scaling[0] = enc.latent.shape[-1]
+            enc.latent_scaling[1] = enc.latent.shape[-2]
+            enc.latent_scaling = enc.latent_scaling / (enc.latent_scaling - 1) * 2.0
+            return enc.latent
+
+        enc.forward = fake_forward
+        poses = synth.scene_cameras(ns)[0]
+        net.encode(torch.zeros(1, ns, 3, H, W), torch.from_numpy(poses)[None], torch.tensor(33.0))
+        with torch.no_grad():
+            out = net(torch.from_numpy(pts), coarse=True, viewdirs=torch.from_numpy(vd))[0]
+        d[tag + "_cfg"] = np.array([nb, cl, ns])
+        d[tag + "_poses"] = poses
+        d[tag + "_out"] = np_(out)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print("wrote", name, {k: v.shape for k, v in d.items() if k.endswith("_out")})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_shims()
@@ -646,6 +685,7 @@ def main():
     fixture_nerf_variants("nerf_variants")
     fixture_yolo_cull("yolo_cull")
     fixture_sched("sched")
+    fixture_mlp_shapes("mlp_shapes")
 
 
 if __name__ == "__main__":
