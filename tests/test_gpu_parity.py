@@ -787,6 +787,51 @@ def test_mlp_shapes_golden(golden, projection):
         assert net.last_mlp_stats(full=True)["projected"] == (projection == "on" and min(cl, nb) > 0), tag
 
 
+def test_randomized_differential_soak():
+    """40 seeded random launches (point counts around tile / CU multiples, 1-4 views, both MLPs): the result must not
+    depend on the kernel shape picked for the launch (bit-exact against a padded launch of the same points, which
+    runs on the other shape or with different tail tiles) and the two evaluation orders must agree within TOL."""
+    rs = np.random.RandomState(2024)
+    H = W = 32
+    nets = {}
+    for ns in (1, 2, 3, 4):
+        c = pconf.default_mv()
+        if ns == 1:   # single view: no combine (conf/default.conf)
+            for k in ("mlp_coarse", "mlp_fine"):
+                c.d["model"][k] = {"type": "resnet", "n_blocks": 3, "d_hidden": 512, "d_out": 4}
+        net = make_model(c["model"]).eval()
+        nb, cl = (3, 1000) if ns == 1 else (5, 3)
+        for mlp, seed in ((net.mlp_coarse, 900 + ns), (net.mlp_fine, 950 + ns)):
+            mlp.load_state_dict({k: torch.from_numpy(v) for k, v in synth.mlp_state(seed, n_blocks=nb, combine_layer=cl).items()})
+        net = net.to(DEV)
+        net.encode(torch.zeros(1, ns, 3, H, W), torch.from_numpy(synth.scene_cameras(ns)[0])[None], torch.tensor(30.0),
+                   latent=torch.from_numpy(synth.latent(960 + ns, ns, 512, H // 2, W // 2)))
+        nets[ns] = net
+    sizes = [1, 31, 32, 33, 63, 64, 65, 100, 2047, 2048, 4097, 8191, 8192, 8193, 16383, 16384 + 64, 20000, 33333]
+    for it in range(40):
+        ns = int(rs.choice([1, 2, 3, 4]))
+        n = int(rs.choice(sizes))
+        coarse = bool(rs.randint(2))
+        net = nets[ns]
+        xyz = dt(rs.uniform(-0.6, 0.6, size=(n, 3)).astype(np.float32))
+        vd = dt(rs.standard_normal((n, 3)).astype(np.float32))
+        pad = int(rs.choice([40000, 70000]))                      # the padded launch runs on 64-sample tiles
+        xyz_p = torch.cat([xyz, dt(rs.uniform(-0.6, 0.6, size=(pad, 3)).astype(np.float32))])
+        vd_p = torch.cat([vd, dt(rs.standard_normal((pad, 3)).astype(np.float32))])
+        res = {}
+        for mode in ("on", "off"):
+            net.set_latent_projection(mode)
+            with torch.no_grad():
+                a = net(xyz[None], coarse=coarse, viewdirs=vd[None])[0]
+                b = net(xyz_p[None], coarse=coarse, viewdirs=vd_p[None])[0][:n]
+            assert torch.equal(a, b), (it, ns, n, mode, float((a - b).abs().max()))
+            assert bool(torch.isfinite(a).all())
+            res[mode] = a
+        scale = max(1.0, float(res["off"][:, 3].max()))
+        assert maxabs(res["on"][:, :3], res["off"][:, :3]) < TOL, (it, ns, n)
+        assert maxabs(res["on"][:, 3], res["off"][:, 3]) < TOL * scale, (it, ns, n)
+
+
 def test_misaligned_rays_are_refused(golden):
     """The fused kernel reads a ray row as two 16-byte words: an unaligned pointer is an argument error,
     not a fault."""
