@@ -787,6 +787,22 @@ def test_mlp_shapes_golden(golden, projection):
         assert net.last_mlp_stats(full=True)["projected"] == (projection == "on" and min(cl, nb) > 0), tag
 
 
+def test_randomized_render_options_vs_oracle(projection):
+    """12 seeded random renderer configurations (sample counts, depth-sample share, lindisp, background, views, ray
+    count incl. non-multiples of every tile size) against the oracle on the same draws."""
+    rs = np.random.RandomState(77)
+    scenes = {ns: small_scene(ns=ns, seed=300 + ns) for ns in (2, 3)}
+    for it in range(12):
+        ns = int(rs.choice([2, 3]))
+        net, sc, rays = scenes[ns]
+        kc = int(rs.choice([8, 16, 33, 64]))
+        kf = int(rs.choice([0, 4, 16, 31]))
+        kfd = int(rs.randint(0, kf + 1)) if kf else 0
+        n = int(rs.choice([1, 7, 40, 65]))
+        sub = rays[torch.from_numpy(rs.choice(rays.shape[0], n, replace=False))]
+        check_render(net, sc, sub, kc, kf, kfd, lindisp=bool(rs.randint(2)), white=bool(rs.randint(2)), max_flips=2)
+
+
 def test_randomized_differential_soak():
     """40 seeded random launches (point counts around tile / CU multiples, 1-4 views, both MLPs): the result must not
     depend on the kernel shape picked for the launch (bit-exact against a padded launch of the same points, which
