@@ -15,36 +15,51 @@ def rows(pattern):
                 yield r
 
 
+def dur_ms(r):
+    return (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+
+
+def frame_rows(pattern):
+    """MLP-kernel rows of the full-frame launches only: bench.py's one-time setup renders 256 and 4096 rays before
+    the steps (code-object load), which must not dilute per-launch means.  Full-frame = at least half as long as the
+    longest MLP dispatch of the pass."""
+    mlp = [r for r in rows(pattern) if "pny_mlp_kernel" in r.get("Kernel_Name", "")]
+    if not mlp:
+        return []
+    longest = max(dur_ms(r) for r in mlp)
+    return [r for r in mlp if dur_ms(r) >= 0.5 * longest]
+
+
 def main(tag):
     src = os.path.join("gpurun_out", "prof_" + tag)
     out = [f"# rocprofv3 summary `{tag}` (bench.py --steps 2 --warmup 1 --cpu-rays 0, 1x MI355X)\n"]
     # ---- kernel trace
     agg = defaultdict(lambda: [0, 0.0, 1e30, 0.0])
-    for r in rows(os.path.join(src, "trace", "**", "*kernel_trace.csv")):
+    trace_pat = os.path.join(src, "trace", "**", "*kernel_trace.csv")
+    frame = frame_rows(trace_pat)
+    for r in list(rows(trace_pat)) + [dict(r, Kernel_Name="pny_mlp_kernel, FULL-FRAME launches only (the bench steps)") for r in frame]:
         name = r["Kernel_Name"].split("(")[0]
-        dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+        dur = dur_ms(r)
         a = agg[name]
         a[0] += 1
         a[1] += dur
         a[2] = min(a[2], dur)
         a[3] = max(a[3], dur)
-    tot = sum(a[1] for a in agg.values()) or 1.0
+    tot = sum(a[1] for k, a in agg.items() if "FULL-FRAME" not in k) or 1.0
     out.append("## Kernel trace (`--kernel-trace --stats`)\n")
     out.append("| kernel | calls | total ms | avg ms | min ms | max ms | % |")
     out.append("|---|---|---|---|---|---|---|")
     for name, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         out.append(f"| `{name[:70]}` | {a[0]} | {a[1]:.3f} | {a[1]/a[0]:.3f} | {a[2]:.3f} | {a[3]:.3f} | {100*a[1]/tot:.2f} |")
     # ---- PMC passes
-    out.append("\n## PMC counters, pny_mlp_kernel dispatches only (separate `--pmc` passes; per-dispatch mean)\n")
+    out.append("\n## PMC counters, full-frame pny_mlp_kernel dispatches only (separate `--pmc` passes; per-dispatch mean)\n")
     out.append("| pass | counter | mean per dispatch | dispatches |")
     out.append("|---|---|---|---|")
     for p in sorted(glob.glob(os.path.join(src, "pmc_*"))):
         if not os.path.isdir(p):
             continue
         acc = defaultdict(lambda: [0, 0.0])
-        for r in rows(os.path.join(p, "**", "*counter_collection.csv")):
-            if "pny_mlp_kernel" not in r.get("Kernel_Name", ""):
-                continue
+        for r in frame_rows(os.path.join(p, "**", "*counter_collection.csv")):
             a = acc[r["Counter_Name"]]
             a[0] += 1
             a[1] += float(r["Counter_Value"])
@@ -59,8 +74,8 @@ def main(tag):
     names = set()
     for cname, pdir in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
         tot = cnt = 0
-        for r in rows(os.path.join(src, pdir, "**", "*counter_collection.csv")):
-            if "pny_mlp_kernel" in r.get("Kernel_Name", "") and r["Counter_Name"] == cname:
+        for r in frame_rows(os.path.join(src, pdir, "**", "*counter_collection.csv")):
+            if r["Counter_Name"] == cname:
                 tot += float(r["Counter_Value"])
                 cnt += 1
                 names.add(r["Kernel_Name"].split("(")[0])
