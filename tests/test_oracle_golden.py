@@ -231,3 +231,37 @@ def test_mlp_shapes(golden):
         out = orc.query(sc, g["xyz"], g["viewdirs"], coarse=True)
         assert maxabs(out[:, :3], g[tag + "_out"][:, :3]) < 2e-6, tag
         assert maxabs(out[:, 3], g[tag + "_out"][:, 3]) < 2e-5, tag
+
+
+def test_training_gradients(golden):
+    """tests/golden/nerf_grads.npz: gradients of the reference's training loss (MSE on coarse.rgb + MSE on fine.rgb,
+    PixelNerfTrainer.py:133-156) w.r.t. every MLP parameter and the latent.  The oracle is written in torch ops, so
+    autograd through it must reproduce them: this pins the checker the backward pass (docs/backward_plan.md) will be
+    held to.  Goldens store a digest per tensor (sum, sum |.|, max |.|, 192 seeded entries)."""
+    from pixel_nerf_yolo_amd import synth
+    g = golden("nerf_grads")
+    seed, ns, H, W = int(g["seed"]), int(g["NS"]), int(g["H"]), int(g["W"])
+    kc, kf, kfd = int(g["Kc"]), int(g["Kf"]), int(g["Kfd"])
+    mc = {k: torch.from_numpy(v).requires_grad_() for k, v in synth.mlp_state(seed * 10 + 1).items()}
+    mf = {k: torch.from_numpy(v).requires_grad_() for k, v in synth.mlp_state(seed * 10 + 2).items()}
+    lat = torch.from_numpy(synth.latent(seed * 10 + 3, ns, 512, H // 2, W // 2)).requires_grad_()
+    sc = orc.Scene(mc, mf, lat, g["poses"], g["focal"], g["c"], W, H)
+    r = orc.render(sc, g["rays"], kc, kf, kfd, g["draw0_rand_like"], g["draw1_rand"], g["draw2_rand_like"],
+                   g["draw3_randn_like"], white_bkgd=True)
+    assert maxabs(r["coarse"]["rgb"].detach(), g["coarse_rgb"]) < 2e-6 and maxabs(r["fine"]["rgb"].detach(), g["fine_rgb"]) < 5e-6
+    gt = torch.from_numpy(g["gt"])
+    loss = torch.nn.functional.mse_loss(r["coarse"]["rgb"], gt) + torch.nn.functional.mse_loss(r["fine"]["rgb"], gt)
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-6
+    loss.backward()
+    grads = {"mlp_coarse." + k: v.grad for k, v in mc.items()}
+    grads.update({"mlp_fine." + k: v.grad for k, v in mf.items()})
+    grads["latent"] = lat.grad
+    assert sorted(grads) == sorted(g["grad_names"].tolist())
+    for name, gr in grads.items():
+        assert gr is not None, name
+        stat, idx, val = g["g:%s:stat" % name], g["g:%s:idx" % name], g["g:%s:val" % name]
+        f = gr.reshape(-1).double()
+        scale = max(float(stat[2]), 1e-12)                               # the tensor's max |gradient|
+        assert float((f[torch.from_numpy(idx)] - torch.from_numpy(val)).abs().max()) < 2e-4 * scale, name
+        assert abs(float(f.abs().sum()) - float(stat[1])) < 2e-4 * float(stat[1]) + 1e-12, name
+        assert abs(float(f.abs().max()) - float(stat[2])) < 2e-4 * scale, name

@@ -670,6 +670,71 @@ def fixture_mlp_shapes(name, seed=17):
     print("wrote", name, {k: v.shape for k, v in d.items() if k.endswith("_out")})
 
 
+GRAD_SAMPLES = 192  # entries kept per gradient tensor (plus its sum, abs-sum and max-abs)
+
+
+def grad_digest(t, rs):
+    """A compact stand-in for a gradient tensor: sum, sum of |.|, max |.| and GRAD_SAMPLES seeded entries."""
+    f = t.detach().reshape(-1).double()
+    idx = rs.choice(f.numel(), size=min(GRAD_SAMPLES, f.numel()), replace=False)
+    return np.array([float(f.sum()), float(f.abs().sum()), float(f.abs().max())]), idx.astype(np.int64), f[torch.from_numpy(idx)].numpy()
+
+
+def fixture_grads(name, seed=19):
+    """Gradients of the reference's training loss (PixelNerfTrainer.calc_losses: MSE on coarse.rgb + MSE on fine.rgb,
+    trainlib/PixelNerfTrainer.py:133-156) w.r.t. every MLP parameter and the latent, on a small 2-view render --
+    the pinned target of the backward pass (docs/backward_plan.md).  Per tensor a digest is stored, not the tensor."""
+    import util
+    from model import make_model
+    from render import NeRFRenderer
+
+    torch.manual_seed(seed)
+    H = W = 32
+    NS, Kc, Kf, Kfd, n_rays = 2, 16, 8, 4, 24
+    net = make_model(model_conf(has_fine=True)).train()
+    load_mlp(net.mlp_coarse, seed * 10 + 1, 512, 4)
+    load_mlp(net.mlp_fine, seed * 10 + 2, 512, 4)
+    lat = torch.from_numpy(synth.latent(seed * 10 + 3, NS, 512, H // 2, W // 2)).requires_grad_()
+    enc = net.encoder
+
+    def fake_forward(x):
+        enc.latent = lat
+        enc.latent_scaling[0] = enc.latent.shape[-1]
+        enc.latent_scaling[1] = enc.latent.shape[-2]
+        enc.latent_scaling = enc.latent_scaling / (enc.latent_scaling - 1) * 2.0
+        return enc.latent
+
+    enc.forward = fake_forward
+    poses, tgt = synth.scene_cameras(NS)
+    focal, c_img = torch.tensor(33.0), torch.tensor([[16.0, 16.0]])
+    net.encode(torch.zeros(1, NS, 3, H, W), torch.from_numpy(poses)[None], focal, c=c_img)
+    rs = np.random.RandomState(seed)
+    allr = util.gen_rays(torch.from_numpy(tgt)[None], W, H, focal, 0.8, 1.8, c=c_img[0])[0].reshape(-1, 8)
+    rays = allr[torch.from_numpy(rs.choice(H * W, n_rays, replace=False))][None]
+    gt = torch.from_numpy(rs.uniform(0, 1, size=(1, n_rays, 3)).astype(np.float32))
+    renderer = NeRFRenderer(n_coarse=Kc, n_fine=Kf, n_fine_depth=Kfd, depth_std=0.01, white_bkgd=True,
+                            eval_batch_size=500).train()
+    with Recorder() as rec:
+        out = renderer(net, rays, want_weights=True)
+    loss = torch.nn.functional.mse_loss(out.coarse.rgb, gt) + torch.nn.functional.mse_loss(out.fine.rgb, gt)
+    loss.backward()
+    d = {"H": H, "W": W, "NS": NS, "Kc": Kc, "Kf": Kf, "Kfd": Kfd, "seed": seed, "poses": poses, "focal": np_(focal),
+         "c": np_(c_img), "rays": np_(rays[0]), "gt": np_(gt[0]), "loss": float(loss),
+         "coarse_rgb": np_(out.coarse.rgb[0]), "fine_rgb": np_(out.fine.rgb[0])}
+    for i, (kind, t) in enumerate(rec.draws):
+        d["draw%d_%s" % (i, kind)] = np_(t)
+    names = []
+    for pre, mlp in (("mlp_coarse.", net.mlp_coarse), ("mlp_fine.", net.mlp_fine)):
+        for k, p in mlp.named_parameters():
+            assert p.grad is not None, pre + k
+            names.append(pre + k)
+            d["g:" + pre + k + ":stat"], d["g:" + pre + k + ":idx"], d["g:" + pre + k + ":val"] = grad_digest(p.grad, rs)
+    d["g:latent:stat"], d["g:latent:idx"], d["g:latent:val"] = grad_digest(lat.grad, rs)
+    d["grad_names"] = np.array(names + ["latent"])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print("wrote", name, "loss %.6f" % float(loss), len(names), "parameter gradients + latent")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_shims()
@@ -686,6 +751,7 @@ def main():
     fixture_yolo_cull("yolo_cull")
     fixture_sched("sched")
     fixture_mlp_shapes("mlp_shapes")
+    fixture_grads("nerf_grads")
 
 
 if __name__ == "__main__":
