@@ -88,10 +88,13 @@ def main(tag):
                              "MLP dispatches; (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md (gfx950 "
                              "halves FETCH_SIZE for 16-B/lane streams); L2 memory-side requests, Infinity-Cache "
                              "hits included"}
-        with open(os.path.join("profiles", "mlp_traffic.json"), "w") as fh:
+        # bench.py reads mlp_traffic.json for the default line only: variant profiles (tag with a suffix after '_')
+        # keep their own file
+        tname = "mlp_traffic.json" if "_" not in tag else "mlp_traffic_%s.json" % tag
+        with open(os.path.join("profiles", tname), "w") as fh:
             json.dump(traffic, fh, indent=1)
         out.append("\nroofline.traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 = %.4g bytes per MLP launch "
-                   "(written to profiles/mlp_traffic.json)" % traffic["bytes_per_launch"])
+                   "(written to profiles/%s)" % (traffic["bytes_per_launch"], tname))
     dst = os.path.join("profiles", tag + "_summary.md")
     with open(dst, "w") as fh:
         fh.write("\n".join(out) + "\n")
