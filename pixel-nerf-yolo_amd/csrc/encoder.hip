@@ -195,6 +195,106 @@ __global__ __launch_bounds__(SPLIT == 1 ? 256 : 512) void conv_mfma_kernel(const
     }
 }
 
+// Pixel-wise linear map as a tiled GEMM: out[p][n] = sum_k in[p][k] * W[n][k] for channel-last rows (the latent
+// projection; K % 32 == 0, cout % 256 == 0).  Same transposed MFMA formulation as everywhere (weights = packed A
+// operand read straight from L2, pixels = B operand), but the B operand is STAGED THROUGH LDS: the 1x1-convolution path
+// reads it with one scattered 16-byte load per lane and k-iteration (64 cache lines per wave instruction, 16 useful
+// bytes each), here a 128-pixel x 32-channel chunk is loaded as whole 128-byte lines (4 lanes per pixel row), written
+// to LDS as float4 bt[k/4][pixel] and read back conflict-free as MFMA fragments; chunks are double-buffered, the
+// global loads of chunk c+1 are in flight during the MFMAs of chunk c.  A workgroup (4 waves) owns 128 pixels x 256
+// outputs, a wave 128 pixels x 64 outputs (2 x 4 tiles of 32x32), so a weight fragment feeds 4 MFMAs per k-step.
+constexpr int PL_PIX = 128, PL_KC = 32, PL_NW = 4;
+
+__global__ __launch_bounds__(64 * PL_NW) void pixel_linear_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                                  float* __restrict__ out, long long npix, int K, int cout) {
+    __shared__ float4 bt[2][PL_KC / 4][PL_PIX + 1];  // +1: spreads the staging writes over the banks
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = lane & 31, hh = lane >> 5;
+    const int nblocks = cout / 256;
+    const long long pb = blockIdx.x / nblocks;
+    const int nb = (int)(blockIdx.x - pb * nblocks);
+    const long long p0 = pb * PL_PIX;
+    const int J = K / 8;
+    // staging assignment: 4 lanes per pixel row, 32 bytes each (2 float4), 2 rows per thread
+    const int srow = tid >> 2, sq = (tid & 3) * 2;
+    auto stage_load = [&](int c, float4 (&v)[2][2]) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            long long p = p0 + srow + 64 * r;
+            if (p >= npix) p = npix - 1;
+            const float4* src = reinterpret_cast<const float4*>(in + (size_t)p * K + (size_t)c * PL_KC) + sq;
+            v[r][0] = src[0];
+            v[r][1] = src[1];
+        }
+    };
+    auto stage_store = [&](int buf, const float4 (&v)[2][2]) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            bt[buf][sq][srow + 64 * r] = v[r][0];
+            bt[buf][sq + 1][srow + 64 * r] = v[r][1];
+        }
+    };
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.f;
+    const int nt0 = nb * 8 + wave * 2;  // this wave's first 32-output tile
+    const float4* wp = reinterpret_cast<const float4*>(w) + (size_t)nt0 * J * 64 + lane;
+    const int nchunks = K / PL_KC;
+    float4 sv[2][2];
+    stage_load(0, sv);
+    stage_store(0, sv);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) stage_load(c + 1, sv);
+        float4 a[PL_KC / 8][2];
+#pragma unroll
+        for (int j = 0; j < PL_KC / 8; ++j)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) a[j][nt] = wp[((size_t)nt * J + (size_t)c * (PL_KC / 8) + j) * 64];
+#pragma unroll
+        for (int j = 0; j < PL_KC / 8; ++j) {
+            float4 b[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) b[mt] = bt[buf][2 * j + hh][32 * mt + m0];
+#define PNY_STEP(cc)                                                                          \
+    _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                          \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                      \
+            acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j][nt].cc, b[mt].cc, acc[nt][mt], 0, 0, 0);
+            PNY_STEP(x)
+            PNY_STEP(y)
+            PNY_STEP(z)
+            PNY_STEP(w)
+#undef PNY_STEP
+        }
+        if (c + 1 < nchunks) {
+            stage_store(buf ^ 1, sv);  // the other buffer: its readers finished before the barrier of the previous chunk
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const long long p = p0 + 32 * mt + m0;
+        if (p >= npix) continue;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = 32 * (nt0 + nt) + 8 * q + 4 * hh;
+                float4 v;
+                v.x = acc[nt][mt][4 * q + 0];
+                v.y = acc[nt][mt][4 * q + 1];
+                v.z = acc[nt][mt][4 * q + 2];
+                v.w = acc[nt][mt][4 * q + 3];
+                *reinterpret_cast<float4*>(out + (size_t)p * cout + n) = v;
+            }
+    }
+}
+
 // (n,3,H,W) -> (n,H,W,4) with a zero 4th channel
 __global__ void image_to_nhwc4_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int hw) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -472,6 +572,17 @@ static bool run_conv(const ConvLayer& L, const float* in, int n, int hin, int wi
 
 bool run_pixel_linear(const ConvLayer& L, const float* in, long long npix, float* out, hipStream_t st) {
     if (npix <= 0 || npix > 0x7fffffffll) return false;
+    // the tiled GEMM wants K in 32-channel chunks and 256-output blocks (the latent projection: K = 512 | 1792,
+    // cout = 512 * view blocks when that is a multiple of 256) and enough pixels to fill tiles; otherwise the generic
+    // 1x1-convolution path
+    if (L.cin_p % PL_KC == 0 && L.cout % 256 == 0 && npix >= 2 * PL_PIX) {
+        const long long blocks = ((npix + PL_PIX - 1) / PL_PIX) * (L.cout / 256);
+        if (blocks <= 0x7fffffffll) {
+            hipLaunchKernelGGL(pixel_linear_kernel, dim3((unsigned)blocks), dim3(64 * PL_NW), 0, st, in, L.w, out, npix,
+                               L.cin_p, L.cout);
+            return hipGetLastError() == hipSuccess;
+        }
+    }
     return run_conv(L, in, 1, 1, (int)npix, nullptr, 0, out, st);
 }
 
