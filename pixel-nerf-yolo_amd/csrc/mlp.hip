@@ -50,6 +50,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef PNY_WDEPTH
 #define PNY_WDEPTH 4  // 8 re-measured with the low-spill build: -1.1 %
 #endif
+#ifndef PNY_WDEPTH32
+#define PNY_WDEPTH32 4  // ring depth of the 8x32 shape (2 measured: -1.3 %)
+#endif
 template <int NT_, int MT_>
 struct Cfg {
     static constexpr int NT = NT_, MT = MT_;
@@ -57,7 +60,7 @@ struct Cfg {
     static constexpr int NW = 16 / NT;       // waves per workgroup
     static constexpr int THREADS = 64 * NW;
     static constexpr int WPS = (NT * MT == 4) ? 2 : 4;           // resident waves per SIMD (VGPR budget 512 / WPS)
-    static constexpr int WDEPTH = (NT == 2 && MT == 1) ? 2 : PNY_WDEPTH;  // weight-ring depth (k-iterations)
+    static constexpr int WDEPTH = (NT == 2 && MT == 1) ? PNY_WDEPTH32 : PNY_WDEPTH;  // weight-ring depth (k-iterations)
     static constexpr int LDS = ACT_KG * TM * 16 + 32 * TM;       // activations + tap table
 };
 
