@@ -47,6 +47,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //   <NT=2, MT=2>:  8 waves, 256 VGPRs, 2 waves/SIMD, 64-sample tile, one workgroup per CU
 //   <NT=1, MT=2>: 16 waves, 128 VGPRs, 4 waves/SIMD, 64-sample tile, one workgroup per CU
 //   <NT=2, MT=1>:  8 waves, 128 VGPRs, 4 waves/SIMD, 32-sample tile, two workgroups per CU
+//   (<NT=4, MT=1>: 4 waves x 256 VGPRs, two workgroups per CU without the 128-register squeeze, was measured too:
+//    -2.7 % against <2,2> -- two workgroups per CU double the weight stream per sample, which costs more than the
+//    overlap of their non-GEMM phases gains)
 #ifndef PNY_WDEPTH
 #define PNY_WDEPTH 4  // 8 re-measured with the low-spill build: -1.1 %
 #endif
