@@ -2,35 +2,46 @@
 """
 bench.py -- rays/sec of the pixelNeRF-YOLO rendering hot path on MI355X (BASELINE.json metric).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1], "C2"): 128x128 render, 3 source views, ResNet-34 encoder,
-64 coarse + 32 fine samples (16 of them depth samples), white background; synthetic images,
-seeded random weights of the reference architecture, cameras on a sphere.
-A "step" = one full frame per rank from resident inputs (source images + 16384 rays in HBM ->
-rgb/depth in HBM): scene encode (ResNet-34 trunk), latent projection (lin_z applied per latent pixel,
-see include/pnyolo.h), coarse sampling, fused MLP, composite, importance sampling + sort, fused MLP,
-composite, then (N > 1) one RCCL all-gather of the rendered (rays, 4) tiles.  Nothing is carried
-over between steps: the per-scene state (latent, projected maps) is rebuilt inside every timed step
-(the reference's eval loop encodes once per object and renders many views; this is the conservative
-reading).  Weak scaling: every rank renders its own frame; value = all rays of all ranks /
-max-over-ranks time.  `encode_ms` / `projection_ms` report the per-scene parts on their own.
+`--gpus N` with N > 1 run plainly (no launcher) starts the N ranks itself: before anything touches the GPU this
+process spawns `python -m torch.distributed.run ...` as a CHILD (never an exec) and relays rank 0's JSON line.
+
+Workloads (BASELINE.json configs; synthetic images, seeded random weights of the reference architecture, cameras on
+a sphere):
+  c2 (default, the bench line)  128x128, 3 source views, ResNet-34 encoder (HIP trunk inside every step), 64 + 32 (16)
+  c3                            the same with L = 1792 "custom"-backbone conditioning (latent supplied: the YOLOv7
+                                backbone is outside the reference tree)
+  c4                            ONE 400x400 frame, L = 1792, 128 + 64 (32): the frame's rays are sharded over the
+                                ranks (each rank generates its own ray range on its device), one RCCL all-gather
+                                of (rays/G, 4) tiles -> STRONG scaling (north_star's multi-GPU case)
+  c5                            8-scene eval batch, one scene per GPU (each rank encodes and renders its own C3
+                                scene, no exchange) -> weak scaling
+A "step" = one full frame from resident inputs (source images / latent + camera parameters in HBM -> rgb/depth in
+HBM): scene encode, latent projection, coarse sampling, fused MLP, composite, importance sampling + sort, fused MLP,
+composite, then (N > 1, c2/c3/c4) one all-gather of the rendered tiles.  Nothing is carried over between steps: the
+per-scene state is rebuilt inside every timed step (the reference encodes once per object and renders many views;
+this is the conservative reading).  c2/c3/c5: every rank renders its own frame; value = all rays of all ranks /
+max-over-ranks time.  c4: value = the frame's rays / max-over-ranks time.
 
 One JSON line on rank 0 with the contract fields plus
-  roofline:     dominant kernel = pny_mlp_kernel; achieved = the GEMM FLOPs the kernel executes
-                (2/MAC, unpadded; DESIGN.md: 1.8668 GFLOP/ray with the projected latent, 2.6218
-                GFLOP/ray -- SURVEY.md 8d -- in the reference's operation order, --projection off)
-                / its HIP-event time measured inside libpnyolo on the launch stream; peak = 157.3
-                TFLOP/s exact-fp32 MFMA (the dtype issued).  `reference_order_tflops` prices the
-                same launches at the reference's FLOP count (not a utilisation figure).
-  cpu_baseline: the oracle (oracle/pnyolo_oracle.py, a port) timed on the host cores on a bounded
-                ray subset of the same frame.
+  roofline      dominant kernel = pny_mlp_kernel.  `achieved` = the GEMM FLOPs the launched kernel variant EXECUTES
+                (2/MAC, unpadded; with the projected latent lin_z has left the kernel: 1.8668 GFLOP/ray at C2 instead
+                of SURVEY.md 8d's 2.6218) / its HIP-event time measured inside libpnyolo on the launch stream;
+                peak = 157.3 TFLOP/s exact-fp32 MFMA; `frac` = achieved / peak is therefore an executed-FLOP
+                UTILISATION.  `frac_survey_formula` = rays/s x SURVEY.md 8d's FLOP/ray / (peak x GPUs), the
+                formula of the scope table: it exceeds `frac` (and can exceed 1) because the projection removes work.
+  roofline_reference_order   (N = 1) the same frame timed with `--projection off`, i.e. the reference's operation
+                order where executed FLOPs = SURVEY.md 8d's count: achieved / frac / ms per launch / rays per s.
+  cpu_baseline  the oracle (oracle/pnyolo_oracle.py, a port) timed on the host cores on a bounded ray subset.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -38,55 +49,83 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 METRIC = "rays/sec (whole node), 64 samples/ray, 3-view 128×128 render"
-H = W = 128
-NS, KC, KF, KFD = 3, 64, 32, 16
-FOCAL, Z_NEAR, Z_FAR = 131.25, 0.8, 1.8
+NS = 3
+FOCAL128, Z_NEAR, Z_FAR = 131.25, 0.8, 1.8
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 
-
-D_LATENT = 512  # 1792 with --workload c3
-
-
-def flop_per_ray(projected=False):
-    """MLP GEMM FLOPs per ray: reference operation order, or with lin_z moved to the per-scene projection."""
-    per_vs = 42 * 512 + (0 if projected else 3 * D_LATENT * 512) + 6 * 512 * 512
-    post = 4 * 512 * 512 + 512 * 4
-    per_sample = 2 * (NS * per_vs + post)
-    return per_sample * (KC + (KC + KF))
-
-
+# name -> (image side, d_latent, latent side, n_coarse, n_fine, n_fine_depth, scaling, description)
 WORKLOADS = {
-    "c2": "C2: 128x128 render, 3 source views, ResNet34 encoder, 64 coarse + 32 fine (16 depth) samples, white bkgd",
-    "c3": "C3: 128x128 render, 3 source views, YOLO-sized conditioning (L=1792 latent at 16x16 supplied through "
-          "set_latent: the YOLOv7 backbone is outside the reference tree), 64 coarse + 32 fine (16 depth) samples",
+    "c2": (128, 512, 64, 64, 32, 16, "weak",
+           "C2: 128x128 render, 3 source views, ResNet34 encoder, 64 coarse + 32 fine (16 depth) samples, white bkgd"),
+    "c3": (128, 1792, 16, 64, 32, 16, "weak",
+           "C3: 128x128 render, 3 source views, YOLO-sized conditioning (L=1792 latent at 16x16 supplied through "
+           "set_latent: the YOLOv7 backbone is outside the reference tree), 64 coarse + 32 fine (16 depth) samples"),
+    "c4": (400, 1792, 50, 128, 64, 32, "strong",
+           "C4: ONE 400x400 frame, 3 source views, L=1792 conditioning (latent at 50x50 supplied), 128 coarse + 64 fine "
+           "(32 depth) samples, the frame's rays sharded across the ranks (per-rank ray generation), one all-gather of "
+           "rendered tiles"),
+    "c5": (128, 1792, 16, 64, 32, 16, "weak",
+           "C5: 8-scene eval batch, one scene per GPU (scene r on rank r: own latent, own cameras, own 128x128 frame), "
+           "L=1792 conditioning, 64 coarse + 32 fine (16 depth) samples, no exchange"),
 }
 
 
+def flop_per_ray(workload, projected=False):
+    """MLP GEMM FLOPs per ray (2/MAC, unpadded): reference operation order, or with lin_z moved to the
+    per-scene projection."""
+    _, L, _, kc, kf, _, _, _ = WORKLOADS[workload]
+    per_vs = 42 * 512 + (0 if projected else 3 * L * 512) + 6 * 512 * 512
+    post = 4 * 512 * 512 + 512 * 4
+    return 2 * (NS * per_vs + post) * (kc + (kc + kf))
+
+
 def describe(workload="c2"):
+    side = WORKLOADS[workload][0]
     return {
-        "metric": METRIC, "unit": "rays/s", "flop_per_ray": flop_per_ray(),
-        "flop_per_ray_projected": flop_per_ray(True),
-        "config": {"workload": WORKLOADS[workload], "rays_per_step_per_gpu": H * W},
+        "metric": METRIC, "unit": "rays/s", "flop_per_ray": flop_per_ray(workload),
+        "flop_per_ray_projected": flop_per_ray(workload, True),
+        "config": {"workload": WORKLOADS[workload][7], "rays_per_frame": side * side},
     }
 
 
+def self_launch(args):
+    """`bench.py --gpus N` outside a launcher: start the N ranks as a child process tree (this process has not touched
+    the GPU and never execs) and relay their output; rank 0 prints the JSON line."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # before anything initialises HIP/HSA (dmabuf IPC for RCCL)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 5; 3 for c4)")
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--cpu-rays", type=int, default=1536, help="ray subset for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-rays", type=int, default=None, help="ray subset for the CPU baseline (0 = skip)")
     ap.add_argument("--projection", choices=["auto", "on", "off"], default="auto",
                     help="latent projection mode of the fused MLP (off = the reference's operation order)")
-    ap.add_argument("--workload", choices=["c2", "c3"], default="c2",
-                    help="c2 = BASELINE.json configs[1] (default, the bench line); c3 = configs[2], L=1792 conditioning")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2",
+                    help="c2 = BASELINE.json configs[1] (default, the bench line); c3/c4/c5 = configs[2..4]")
+    ap.add_argument("--no-reference-order", action="store_true", help="skip the --projection off leg of the N=1 line")
     ap.add_argument("--describe", action="store_true", help="print the workload description and exit (no GPU)")
     args = ap.parse_args()
-    global D_LATENT
-    D_LATENT = 1792 if args.workload == "c3" else 512
+    wl = args.workload
+    side, d_latent, lat_side, KC, KF, KFD, scaling, wl_text = WORKLOADS[wl]
+    if args.steps is None:
+        args.steps = 3 if wl == "c4" else 5
+    if args.cpu_rays is None:
+        args.cpu_rays = 256 if wl == "c4" else 1536
     if args.describe:
-        print(json.dumps(describe(args.workload)))
-        return
+        print(json.dumps(describe(wl)))
+        return 0
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
 
     import numpy as np
     import torch
@@ -94,47 +133,51 @@ def main():
 
     import pnyolo_pkg
     pnyolo_pkg.load()
-    from pixel_nerf_yolo_amd import conf as pconf, synth
+    from pixel_nerf_yolo_amd import conf as pconf, dist as pdist, synth
     from pixel_nerf_yolo_amd.model import make_model
     from pixel_nerf_yolo_amd.render import NeRFRenderer
-    from pixel_nerf_yolo_amd.util import gen_rays
+    from pixel_nerf_yolo_amd.util import gen_rays_range
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path for the product)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
+    n_ranks_seen = dist.get_world_size() if dist.is_initialized() else 1
 
-    # ---- scene: weights, encoder, cameras
+    H = W = side
+    focal_v = FOCAL128 * side / 128.0
+    # ---- scene: weights, encoder / latent, cameras.  c5: rank r holds scene r (own weights are shared, own latent)
+    scene_id = rank if wl == "c5" else 0
     mconf = pconf.default_mv()
-    if args.workload == "c3":
+    if d_latent != 512:
         mconf.d["model"]["encoder"]["backbone"] = "custom"   # d_latent = 1792 (reference custom_encoder.py:22)
     net = make_model(mconf["model"]).eval()
     sd = {}
-    sd.update({"mlp_coarse." + k: v for k, v in synth.mlp_state(71, d_latent=D_LATENT).items()})
-    sd.update({"mlp_fine." + k: v for k, v in synth.mlp_state(72, d_latent=D_LATENT).items()})
-    if args.workload == "c2":
+    sd.update({"mlp_coarse." + k: v for k, v in synth.mlp_state(71, d_latent=d_latent).items()})
+    sd.update({"mlp_fine." + k: v for k, v in synth.mlp_state(72, d_latent=d_latent).items()})
+    if wl == "c2":
         sd.update(synth.resnet34_state(74, residual_gain=0.25))   # latent O(1), like a trained trunk
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
     net = net.to(dev)
     net.set_latent_projection(args.projection)
-    src, _ = synth.scene_cameras(NS)
-    tgt = synth.pose_spherical(120.0 + 10.0 * rank, -20.0, 1.3)
-    images = torch.from_numpy(synth.images(75, NS, H, W)).to(dev)
-    focal, c = torch.tensor(FOCAL), torch.tensor([[W * 0.5, H * 0.5]])
+    src, _ = synth.scene_cameras(NS, radius=1.3 + 0.02 * scene_id)
+    # weak-scaling workloads: every rank renders its own target view; c4: ONE view for all ranks
+    tgt = synth.pose_spherical(120.0 + (0.0 if wl == "c4" else 10.0 * rank), -20.0, 1.3)
+    images = torch.from_numpy(synth.images(75, NS, H, W)).to(dev) if wl == "c2" else torch.zeros(NS, 3, H, W, device=dev)
+    focal, c = torch.tensor(focal_v), torch.tensor([[W * 0.5, H * 0.5]])
     poses = torch.from_numpy(src)[None]
-
-    lat_in = torch.from_numpy(synth.latent(76, NS, 1792, 16, 16)).to(dev) if args.workload == "c3" else None
+    lat_in = None
+    if wl != "c2":   # the backbone's output is an input
+        lat_in = torch.from_numpy(synth.latent(76 + scene_id, NS, d_latent, lat_side, lat_side)).to(dev)
 
     def encode():
-        net.encode(images[None], poses, focal, c=c, latent=lat_in)   # c3: the backbone's output is an input
+        net.encode(images[None], poses, focal, c=c, latent=lat_in)
 
     encode()
     torch.cuda.synchronize()
@@ -155,18 +198,39 @@ def main():
             torch.cuda.synchronize()
             projection_ms += (time.perf_counter() - t0) / 3 * 1e3
 
-    rays = gen_rays(torch.from_numpy(tgt)[None].to(dev), W, H, focal, Z_NEAR, Z_FAR, c=c[0]).reshape(1, -1, 8)
-    n_rays = rays.shape[1]
+    n_frame = H * W
+    if wl == "c4":
+        lo, hi, per = pdist.shard_bounds(n_frame, world, rank)       # this rank's ray range of the ONE frame
+    else:
+        lo, hi, per = 0, n_frame, n_frame                            # own whole frame
+    n_rays = hi - lo
+    pose_t = torch.from_numpy(tgt)[None]
+
+    def make_rays():
+        return gen_rays_range(pose_t, W, H, focal, Z_NEAR, Z_FAR, lo, n_rays, c=c[0], device=dev).reshape(1, -1, 8)
+
+    rays = make_rays()
     ren = NeRFRenderer(n_coarse=KC, n_fine=KF, n_fine_depth=KFD, depth_std=0.01, white_bkgd=True).eval()
     par = ren.bind_parallel(net, None, simple_output=True).eval()
-    gathered = torch.empty(world * n_rays, 4, device=dev) if world > 1 else None
+    exchange = world > 1 and wl in ("c2", "c3")   # c4 exchanges inside render_frame_sharded, c5 not at all
+    gathered = torch.empty(world * per, 4, device=dev) if exchange else None
+    tile = torch.zeros(per, 4, device=dev) if exchange else None
+
+    def render_range(r):
+        with torch.no_grad():
+            rgb, depth = par(r[None])
+        return rgb[0], depth[0]
 
     def step():
         encode()                          # per-scene state is rebuilt inside the step (module docstring)
+        if wl == "c4":
+            # the product's sharded-frame path: per-rank ray generation for [lo, hi), render, one all-gather
+            return pdist.render_frame_sharded(render_range, tgt, W, H, focal, Z_NEAR, Z_FAR, c=c[0], device=dev)
         with torch.no_grad():
             rgb, depth = par(rays)
-        if world > 1:
-            tile = torch.cat([rgb[0], depth[0][:, None]], dim=1)
+        if exchange:
+            tile[:n_rays, :3] = rgb[0]
+            tile[:n_rays, 3] = depth[0]
             dist.all_gather_into_tensor(gathered, tile)
         return rgb, depth
 
@@ -180,38 +244,40 @@ def main():
     with torch.no_grad():
         par(rays[:, :256].contiguous())   # 8x32 and (fine pass) 8x64 shapes, projected variant when enabled
         par(rays[:, :4096].contiguous())
-    if world > 1:
-        dist.all_gather_into_tensor(gathered, torch.zeros(n_rays, 4, device=dev))
+    if exchange:
+        dist.all_gather_into_tensor(gathered, tile)
     fence()
+
+    def timed(steps):
+        """K steps between fences; returns (elapsed s max over ranks, summed MLP kernel stats, last outputs)."""
+        net.enable_kernel_timing(True)
+        fence()
+        t0 = time.perf_counter()
+        acc = dict(ms=0.0, flops=0.0, ref=0.0, launches=0, projected=False)
+        for _ in range(steps):
+            rgb, depth = step()
+            # HIP-event times of this step's MLP launches (recorded on the launch stream inside
+            # libpnyolo; reading them waits for the step, which the next step depends on anyway)
+            st = net.last_mlp_stats(full=True)
+            acc["flops"] += st["flops"]
+            acc["ref"] += st["flops_reference"]
+            acc["ms"] += st["kernel_ms"]
+            acc["launches"] += st["launches"]
+            acc["projected"] = acc["projected"] or st["projected"]
+        fence()
+        elapsed = time.perf_counter() - t0
+        net.enable_kernel_timing(False)
+        if world > 1:
+            tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        return elapsed, acc, rgb, depth
 
     for _ in range(args.warmup):
         step()
-    net.enable_kernel_timing(True)
-    fence()
-    t0 = time.perf_counter()
-    kern_ms = 0.0
-    kern_flops = 0.0
-    ref_flops = 0.0
-    launches = 0
-    projected = False
-    for _ in range(args.steps):
-        rgb, depth = step()
-        # HIP-event times of this step's MLP launches (recorded on the launch stream inside
-        # libpnyolo; reading them waits for the step, which the next step depends on anyway)
-        st = net.last_mlp_stats(full=True)
-        kern_flops += st["flops"]
-        ref_flops += st["flops_reference"]
-        kern_ms += st["kernel_ms"]
-        launches += st["launches"]
-        projected = projected or st["projected"]
-    fence()
-    elapsed = time.perf_counter() - t0
-    net.enable_kernel_timing(False)
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed, acc, rgb, depth = timed(args.steps)
     assert bool(torch.isfinite(rgb).all()) and bool(torch.isfinite(depth).all())
+    projected = acc["projected"]
 
     # HBM-side traffic of the dominant kernel cannot be counted from inside this process: it is the
     # committed rocprofv3 PMC measurement of the same command (tools/profile_gpu.sh -> profiles/mlp_traffic.json)
@@ -219,39 +285,69 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "mlp_traffic.json")) as fh:
             tj = json.load(fh)
-        if bool(tj.get("projected_latent")) == bool(projected) and args.workload == "c2":
+        if bool(tj.get("projected_latent")) == bool(projected) and wl == "c2":
             traffic, traffic_note = tj["bytes_per_launch"], "%s: %s" % (tj["tag"], tj["method"])
     except (OSError, ValueError, KeyError):
         pass
 
-    total_rays = world * n_rays * args.steps
-    value = total_rays / elapsed
-    achieved = kern_flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else None
+    rays_per_step = n_frame if wl == "c4" else world * n_frame
+    value = rays_per_step * args.steps / elapsed
+
+    def roof(a, rays_per_s, n_gpus):
+        ach = a["flops"] / (a["ms"] * 1e-3) / 1e12 if a["ms"] > 0 else None
+        return {
+            "bound": "mfma", "kernel": "pny_mlp_kernel", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": (ach / PEAK_F32_MFMA_TFLOPS) if ach else None,
+            "frac_is": "executed-FLOP utilisation of this rank's MLP launches (HIP events on the launch stream)",
+            "frac_survey_formula": rays_per_s * flop_per_ray(wl, False) / (PEAK_F32_MFMA_TFLOPS * 1e12 * n_gpus),
+            "launches": a["launches"], "avg_launch_ms": (a["ms"] / a["launches"]) if a["launches"] else None,
+            "flops_per_launch": (a["flops"] / a["launches"]) if a["launches"] else None,
+            "projected_latent": a["projected"],
+            "reference_order_tflops": (a["ref"] / (a["ms"] * 1e-3) / 1e12) if a["ms"] > 0 else None,
+        }
+
+    rl = roof(acc, value, world)
+    rl.update({"traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_note})
     out = {
-        "metric": METRIC, "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": dict(describe(args.workload)["config"], n_views=NS, n_coarse=KC, n_fine=KF, n_fine_depth=KFD,
-                       global_rays_per_step=world * n_rays,
-                       parallelism="rays sharded, 1 process/GPU, dp%d, 1 all-gather/frame" % world),
+        "metric": METRIC, "value": value, "unit": "rays/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": dict(describe(wl)["config"], n_views=NS, n_coarse=KC, n_fine=KF, n_fine_depth=KFD,
+                       global_rays_per_step=rays_per_step, rays_per_step_this_rank=n_rays,
+                       parallelism={"c4": "one frame's rays sharded over %d ranks (per-rank ray generation), 1 process/GPU, "
+                                          "1 all-gather/frame" % world,
+                                    "c5": "scene per GPU, %d ranks, no exchange" % world}.get(
+                                        wl, "frame per GPU, 1 process/GPU, dp%d, 1 all-gather/frame" % world)),
         "encode_ms": encode_ms, "projection_ms": projection_ms,
-        "flop_per_ray": flop_per_ray(projected), "flop_per_ray_reference_order": flop_per_ray(False),
-        "roofline": {
-            "bound": "mfma", "kernel": "pny_mlp_kernel", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": (achieved / PEAK_F32_MFMA_TFLOPS) if achieved else None,
-            "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_note, "launches": launches,
-            "avg_launch_ms": (kern_ms / launches) if launches else None,
-            "flops_per_launch": (kern_flops / launches) if launches else None,
-            "projected_latent": projected,
-            "reference_order_tflops": (ref_flops / (kern_ms * 1e-3) / 1e12) if kern_ms > 0 else None,
-        },
+        "flop_per_ray": flop_per_ray(wl, projected), "flop_per_ray_reference_order": flop_per_ray(wl, False),
+        "roofline": rl,
     }
+
+    if world == 1 and args.projection != "off" and not args.no_reference_order:
+        # the same frame in the reference's operation order (lin_z per sample): executed FLOPs = SURVEY.md 8d's count
+        net.set_latent_projection("off")
+        step()
+        k_ref = max(2, min(3, args.steps))
+        e2, a2, _, _ = timed(k_ref)
+        r2 = roof(a2, rays_per_step * k_ref / e2, 1)
+        out["roofline_reference_order"] = {
+            "achieved": r2["achieved"], "frac": r2["frac"], "unit": "TFLOP/s", "peak": PEAK_F32_MFMA_TFLOPS,
+            "ms_per_launch": r2["avg_launch_ms"], "rays_per_s": rays_per_step * k_ref / e2, "steps": k_ref,
+            "flop_per_ray": flop_per_ray(wl, False), "projected_latent": a2["projected"],
+            "note": "--projection off: lin_z per (sample, view) as the reference orders it; not the bench value"}
+        net.set_latent_projection(args.projection)
 
     if rank == 0 and args.cpu_rays > 0 and world == 1:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import pnyolo_oracle as orc  # CPU baseline leg: the oracle as the thing timed beside the GPU
-        lat = net.latent(0).cpu().numpy()
-        sc = orc.Scene(synth.mlp_state(71, d_latent=D_LATENT), synth.mlp_state(72, d_latent=D_LATENT), lat, src, focal, c,
+        encode()
+        if wl == "c2":   # the oracle runs its OWN trunk on the same images: the parity leg below is end to end
+            t0 = time.perf_counter()
+            lat = orc.spatial_encoder(synth.resnet34_state(74, residual_gain=0.25), images.cpu().numpy())[0].numpy()
+            cpu_encode_s = time.perf_counter() - t0
+        else:
+            lat, cpu_encode_s = net.latent(0).cpu().numpy(), None   # the backbone's output is an input on both sides
+        sc = orc.Scene(synth.mlp_state(71, d_latent=d_latent), synth.mlp_state(72, d_latent=d_latent), lat, src, focal, c,
                        W, H)
         nb = args.cpu_rays
         rs = np.random.RandomState(0)
@@ -264,7 +360,8 @@ def main():
         cpu_out = orc.render(sc, sub, KC, KF, KFD, *draws, chunk=50000)
         cpu_s = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": nb / cpu_s, "unit": "rays/s", "cores": torch.get_num_threads(),
-                               "kind": "port", "sample": "%d random rays of the same %s frame, %.1f s" % (nb, args.workload.upper(), cpu_s)}
+                               "kind": "port", "sample": "%d random rays of the same %s frame, %.1f s" % (nb, wl.upper(), cpu_s),
+                               "encode_s": cpu_encode_s}
         # the same rays and draws through the HIP path: the checker's output beside the product's (not timed)
         ren.draws = dict(u_coarse=draws[0], u_fine=draws[1], u_fine2=draws[2], g_depth=draws[3])
         with torch.no_grad():
@@ -279,10 +376,11 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -18,6 +18,11 @@
  *   - a pny_model owns packed weights; a pny_scene owns the per-scene state the reference keeps
  *     in module buffers after encode() (latent, world->cam poses, intrinsics) plus a grow-only
  *     workspace.  One model / scene per device and per caller thread.
+ *   - streams: the calls on one scene are ordered by the stream they are enqueued on.  A call that
+ *     arrives on a different stream than the previous call on the same scene is ordered behind it by
+ *     the library (one event record + stream wait, paid on the switch only), so a scene may migrate
+ *     between streams; two streams must not drive the same scene concurrently from two threads.
+ *     The previous stream must still exist at the switch or have been destroyed after draining.
  */
 #ifndef PNYOLO_H
 #define PNYOLO_H
@@ -29,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PNY_ABI_VERSION 3
+#define PNY_ABI_VERSION 4
 
 typedef enum pny_status {
     PNY_OK = 0,
@@ -87,7 +92,10 @@ void pny_scene_destroy(pny_scene* s);
 /* Camera half of PixelNeRFNet.encode (src/model/models.py:115-148).
  * poses_host (ns,4,4): cam->world, inverted here to world->cam [R^T | -R^T t]; in YOLO mode
  * they are world->cam extrinsics and used as given.  focal_host (nf,2), c_host (nc,2) with
- * nf, nc in {1, ns}; fy is negated here in non-YOLO mode as the reference does. */
+ * nf, nc in {1, ns}; fy is negated here in non-YOLO mode as the reference does.
+ * Host-only: the cameras are kept in the handle and travel to the device as kernel arguments of each
+ * later launch (no device copy, no synchronisation; launches already enqueued keep the cameras they
+ * were launched with). */
 int pny_scene_set_cameras(pny_scene* s, const float* poses_host, int ns, const float* focal_host, int nf,
                           const float* c_host, int nc, int width, int height);
 /* Encoder bypass: installs a latent (ns, L, Hl, Wl) NCHW as SpatialEncoder.forward would leave
@@ -107,6 +115,13 @@ int pny_scene_latent_shape(pny_scene* s, int* ns, int* channels, int* hl, int* w
 int pny_gen_rays(const float* poses_host, int b, int width, int height, const float focal[2],
                  const float c[2], float z_near, float z_far, int yolo_mode, float* out_dev,
                  pny_stream stream);
+/* The same for rays [first_ray, first_ray + n_rays) of the flattened (b, H, W) pixel grid only:
+ * out_dev (n_rays, 8), 16-byte aligned.  This is how a rank of a ray-sharded render produces its own
+ * slice of a frame on its own device (no scatter of rays).  Asynchronous; the camera
+ * blocks travel as kernel arguments (no device allocation, no copy, no synchronisation). */
+int pny_gen_rays_range(const float* poses_host, int b, int width, int height, const float focal[2],
+                       const float c[2], float z_near, float z_far, int yolo_mode, int64_t first_ray,
+                       int64_t n_rays, float* out_dev, pny_stream stream);
 
 /* PixelNeRFNet.forward for one scene (src/model/models.py:153-318):
  * xyz_dev, viewdirs_dev (n,3) world space -> out_dev (n,d_out) = [sigmoid rgb, relu sigma]

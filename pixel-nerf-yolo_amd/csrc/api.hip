@@ -77,7 +77,8 @@ struct pny_scene {
     int width = 0, height = 0;
     bool have_cams = false, have_latent = false;
     int cam_ns = 0;
-    DevBuf cams, latent, work, scratch, enc_work;
+    Cam cams[MAX_VIEWS];  // host copy; handed to every MLP launch as kernel arguments
+    DevBuf latent, work, scratch, enc_work;
     // projected latent of the coarse [0] / fine [1] MLP (see ensure_projection)
     DevBuf zp[2];
     bool zp_valid[2] = {false, false};
@@ -91,7 +92,32 @@ struct pny_scene {
     int ev_used = 0;
     double last_flops = 0.0;
     int last_launches = 0;
+    // stream the last call on this scene was enqueued on (see enter_stream)
+    hipStream_t last_stream = nullptr;
+    bool has_last_stream = false;
+    hipEvent_t order_ev = nullptr;
 };
+
+// A scene's state (latent, projected maps, workspace, cross-view slab) is written and read by the kernels of
+// successive calls without any host synchronisation, which is only ordered if those calls share a stream.  When a
+// call arrives on a DIFFERENT stream than the previous call on the same scene, the new stream is made to wait for
+// everything the previous call enqueued (one event record + one stream wait, paid only on a stream switch).
+static int enter_stream(pny_scene* s, hipStream_t st) {
+    if (s->has_last_stream && s->last_stream != st) {
+        if (!s->order_ev && hipEventCreateWithFlags(&s->order_ev, hipEventDisableTiming) != hipSuccess) {
+            s->order_ev = nullptr;
+            return hip_fail(hipGetLastError(), "hipEventCreate(stream order)");
+        }
+        if (hipEventRecord(s->order_ev, s->last_stream) == hipSuccess) {
+            PNY_HIP(hipStreamWaitEvent(st, s->order_ev, 0));
+        } else {
+            (void)hipGetLastError();  // the previous stream no longer exists: its work has drained
+        }
+    }
+    s->last_stream = st;
+    s->has_last_stream = true;
+    return 0;
+}
 
 // ---------------------------------------------------------------------------------- packing
 // A-operand order of v_mfma_f32_32x32x2_f32 for H^T = W X^T (see mlp.hip): for k-iteration j (8
@@ -311,7 +337,6 @@ int pny_scene_create(pny_scene** out, pny_model* m) {
 
 void pny_scene_destroy(pny_scene* s) {
     if (!s) return;
-    s->cams.release();
     s->latent.release();
     s->work.release();
     s->scratch.release();
@@ -319,6 +344,7 @@ void pny_scene_destroy(pny_scene* s) {
     s->zp[0].release();
     s->zp[1].release();
     for (auto e : s->ev) (void)hipEventDestroy(e);
+    if (s->order_ev) (void)hipEventDestroy(s->order_ev);
     delete s;
 }
 
@@ -328,11 +354,9 @@ int pny_scene_set_cameras(pny_scene* s, const float* poses, int ns, const float*
     if (ns < 1 || ns > MAX_VIEWS) return fail(PNY_ERR_ARG, "pny_scene_set_cameras: ns out of range [1,16]");
     if ((nf != 1 && nf != ns) || (nc != 1 && nc != ns)) return fail(PNY_ERR_ARG, "pny_scene_set_cameras: focal / c count must be 1 or ns");
     if (width < 1 || height < 1) return fail(PNY_ERR_ARG, "pny_scene_set_cameras: bad image size");
-    PNY_HIP(hipSetDevice(s->m->desc.device));
-    std::vector<Cam> cams(ns);
     for (int v = 0; v < ns; ++v) {
         const float* P = poses + 16 * v;
-        Cam& cm = cams[v];
+        Cam& cm = s->cams[v];
         if (!s->m->desc.yolo) {
             // reference models.py:116-118: rot = R^T, trans = -(R^T t) via bmm (fp32)
             for (int i = 0; i < 3; ++i) {
@@ -352,9 +376,6 @@ int pny_scene_set_cameras(pny_scene* s, const float* poses, int ns, const float*
         cm.cx = cc[0];
         cm.cy = cc[1];
     }
-    int rc;
-    if ((rc = s->cams.reserve(sizeof(Cam) * MAX_VIEWS))) return rc;
-    PNY_HIP(hipMemcpy(s->cams.p, cams.data(), sizeof(Cam) * ns, hipMemcpyHostToDevice));
     s->cam_ns = ns;
     s->width = width;
     s->height = height;
@@ -369,6 +390,7 @@ int pny_scene_set_latent(pny_scene* s, const float* latent_dev, int ns, int chan
     if ((long long)hl * wl * channels >= (1ll << 31)) return fail(PNY_ERR_ARG, "pny_scene_set_latent: latent too large for 32-bit tap offsets");
     PNY_HIP(hipSetDevice(s->m->desc.device));
     int rc;
+    if ((rc = enter_stream(s, (hipStream_t)stream))) return rc;
     if ((rc = s->latent.reserve((size_t)ns * channels * hl * wl * sizeof(float)))) return rc;
     launch_nchw_to_nhwc(latent_dev, s->latent.f(), ns, channels, hl * wl, (hipStream_t)stream);
     PNY_HIP(hipGetLastError());
@@ -392,6 +414,7 @@ int pny_scene_encode(pny_scene* s, const float* images_dev, int ns, int height, 
     encoder_latent_size(height, width, &hl, &wl);
     if ((long long)hl * wl * 512 >= (1ll << 31)) return fail(PNY_ERR_ARG, "pny_scene_encode: latent too large for 32-bit tap offsets");
     int rc;
+    if ((rc = enter_stream(s, (hipStream_t)stream))) return rc;
     if ((rc = s->latent.reserve((size_t)ns * 512 * hl * wl * sizeof(float)))) return rc;
     const bool pool = s->m->desc.enc_use_first_pool != 0;
     if ((rc = s->enc_work.reserve(encoder_workspace_bytes(ns, height, width, pool)))) return rc;
@@ -420,6 +443,7 @@ int pny_scene_get_latent(pny_scene* s, float* latent_dev, pny_stream stream) {
     if (!s || !latent_dev) return fail(PNY_ERR_ARG, "pny_scene_get_latent: null argument");
     if (!s->have_latent) return fail(PNY_ERR_STATE, "pny_scene_get_latent: no latent");
     PNY_HIP(hipSetDevice(s->m->desc.device));
+    if (int rc = enter_stream(s, (hipStream_t)stream)) return rc;
     launch_nhwc_to_nchw(s->latent.f(), latent_dev, s->ns, s->L, s->hl * s->wl, (hipStream_t)stream);
     PNY_HIP(hipGetLastError());
     return PNY_OK;
@@ -453,11 +477,15 @@ static bool invert4(const float* m, double* inv) {
     return true;
 }
 
-int pny_gen_rays(const float* poses_host, int b, int width, int height, const float focal[2], const float c[2],
-                 float z_near, float z_far, int yolo_mode, float* out_dev, pny_stream stream) {
-    if (!poses_host || !focal || !c || !out_dev) return fail(PNY_ERR_ARG, "pny_gen_rays: null argument");
+int pny_gen_rays_range(const float* poses_host, int b, int width, int height, const float focal[2], const float c[2],
+                       float z_near, float z_far, int yolo_mode, int64_t first_ray, int64_t n_rays, float* out_dev,
+                       pny_stream stream) {
+    if (!poses_host || !focal || !c || (!out_dev && n_rays > 0)) return fail(PNY_ERR_ARG, "pny_gen_rays: null argument");
     if (b < 0 || width < 1 || height < 1) return fail(PNY_ERR_ARG, "pny_gen_rays: bad shape");
-    if (b == 0) return PNY_OK;
+    const int64_t total = (int64_t)b * width * height;
+    if (first_ray < 0 || n_rays < 0 || first_ray + n_rays > total) return fail(PNY_ERR_ARG, "pny_gen_rays: ray range outside the (b, h, w) grid");
+    if (n_rays == 0) return PNY_OK;
+    if (reinterpret_cast<uintptr_t>(out_dev) & 15) return fail(PNY_ERR_ARG, "pny_gen_rays: out_dev must be 16-byte aligned");
     std::vector<float> cam((size_t)b * 16);
     for (int i = 0; i < b; ++i) {
         const float* P = poses_host + 16 * i;
@@ -485,20 +513,17 @@ int pny_gen_rays(const float* poses_host, int b, int width, int height, const fl
             o[15] = (float)(-(double)c[1] / focal[1]);
         }
     }
-    // small per-call parameter block: staged through a stream-ordered device allocation
-    float* dcam = nullptr;
-    hipStream_t st = (hipStream_t)stream;
-    PNY_HIP(hipMalloc((void**)&dcam, cam.size() * sizeof(float)));
-    hipError_t e = hipMemcpyAsync(dcam, cam.data(), cam.size() * sizeof(float), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) {
-        launch_gen_rays(dcam, b, width, height, z_near, z_far, yolo_mode, out_dev, st);
-        e = hipGetLastError();
-    }
-    hipError_t e2 = hipStreamSynchronize(st);  // cam is a host temporary and dcam is freed below
-    (void)hipFree(dcam);
-    if (e != hipSuccess) return hip_fail(e, "pny_gen_rays launch");
-    if (e2 != hipSuccess) return hip_fail(e2, "pny_gen_rays sync");
+    // the per-image parameter blocks travel as kernel arguments: nothing is staged, allocated or synchronised here
+    launch_gen_rays(cam.data(), b, width, height, z_near, z_far, yolo_mode, out_dev, (hipStream_t)stream, first_ray, n_rays);
+    PNY_HIP(hipGetLastError());
     return PNY_OK;
+}
+
+int pny_gen_rays(const float* poses_host, int b, int width, int height, const float focal[2], const float c[2],
+                 float z_near, float z_far, int yolo_mode, float* out_dev, pny_stream stream) {
+    if (b < 0 || width < 1 || height < 1) return fail(PNY_ERR_ARG, "pny_gen_rays: bad shape");
+    return pny_gen_rays_range(poses_host, b, width, height, focal, c, z_near, z_far, yolo_mode, 0,
+                              (int64_t)b * width * height, out_dev, stream);
 }
 
 }  // extern "C"
@@ -570,7 +595,7 @@ static int run_mlp(pny_scene* s, int mode, const float* xyz, const float* dirs, 
     if ((rc = ensure_projection(s, fine_w ? 1 : 0, n_points, st, &a.zp))) return rc;
     a.zp_stride = view_blocks(d) * HID;
     a.tap_stride = a.zp ? a.zp_stride : s->L;
-    a.cams = reinterpret_cast<const Cam*>(s->cams.p);
+    memcpy(a.cams, s->cams, sizeof(Cam) * (size_t)s->ns);
     a.xyz = xyz;
     a.dirs = dirs;
     a.rays = rays;
@@ -645,6 +670,7 @@ int pny_query(pny_scene* s, const float* xyz_dev, const float* viewdirs_dev, int
     if ((rc = check_ready(s, "pny_query"))) return rc;
     if (n < 0 || (n > 0 && (!xyz_dev || !viewdirs_dev || !out_dev))) return fail(PNY_ERR_ARG, "pny_query: bad argument");
     PNY_HIP(hipSetDevice(s->m->desc.device));
+    if ((rc = enter_stream(s, (hipStream_t)stream))) return rc;
     begin_call(s);
     return run_mlp(s, 0, xyz_dev, viewdirs_dev, nullptr, nullptr, 1, n, coarse, out_dev, (hipStream_t)stream);
 }
@@ -705,6 +731,7 @@ int pny_render(pny_scene* s, const float* rays_dev, int64_t n, const pny_render_
     if (n == 0) return PNY_OK;
     PNY_HIP(hipSetDevice(s->m->desc.device));
     hipStream_t st = (hipStream_t)stream;
+    if ((rc = enter_stream(s, st))) return rc;
     begin_call(s);
     const int kc = o->n_coarse, kt = o->n_coarse + o->n_fine;
     // workspace carve (floats): z_c, samp_c, w_c, rgb_c(3)+depth_c, z_f, samp_f
@@ -752,6 +779,7 @@ int pny_yolo_render(pny_scene* s, const float* rays_dev, int64_t n, int n_coarse
     if (n == 0) return PNY_OK;
     PNY_HIP(hipSetDevice(d.device));
     hipStream_t st = (hipStream_t)stream;
+    if ((rc = enter_stream(s, st))) return rc;
     begin_call(s);
     const size_t nz = ((size_t)n * n_coarse + 63) & ~(size_t)63;
     if ((rc = s->work.reserve((nz + (size_t)n * n_coarse * d.d_out) * sizeof(float)))) return rc;
@@ -784,6 +812,7 @@ int pny_scene_project(pny_scene* s, pny_stream stream) {
     if (!s->m->has_zproj) return PNY_OK;  // no per-view blocks: nothing to project
     if (s->zp_mode == PNY_PROJECTION_OFF) return fail(PNY_ERR_STATE, "pny_scene_project: projection is switched off for this scene");
     PNY_HIP(hipSetDevice(s->m->desc.device));
+    if ((rc = enter_stream(s, (hipStream_t)stream))) return rc;
     const int keep = s->zp_mode;
     s->zp_mode = PNY_PROJECTION_ON;
     const float* zp = nullptr;

@@ -48,7 +48,6 @@ struct MlpArgs {
     const float* zp;
     int zp_stride;
     int tap_stride;       // floats per pixel of the map the taps address (L, or zp_stride)
-    const Cam* cams;      // NS entries
     // point source: mode 0 = explicit points, mode 1 = rays + depths (point = o + z d)
     const float* xyz;
     const float* dirs;
@@ -65,6 +64,9 @@ struct MlpArgs {
     float freq_factor;
     float sx, sy;     // latent_scaling / image_size (reference encoder.py:97)
     int n_tiles;
+    // Source-view cameras travel in the kernel-argument segment (NS entries used; 64 B each): a launch carries its own
+    // copy, so pny_scene_set_cameras touches no device memory (no copy, no synchronisation, no stream to order against)
+    Cam cams[MAX_VIEWS];
 };
 
 enum { MLP_8x64 = 0, MLP_16x64 = 1, MLP_8x32 = 2 };  // kernel shapes (mlp.hip Cfg)
@@ -83,8 +85,8 @@ void launch_sample_fine(const float* rays, const float* zc, const float* w, cons
                         int kc, int kf, int kfd, float depth_std, int lindisp, const float* u, const float* u2,
                         const float* g, uint64_t seed, float* zout, hipStream_t st);
 void launch_yolo_aggregate(const float* raw, long long n, int k, int na, float* out, hipStream_t st);
-void launch_gen_rays(const float* cam16, int b, int w, int h, float znear, float zfar, int yolo, float* out,
-                     hipStream_t st);
+void launch_gen_rays(const float* cam16_host, int b, int w, int h, float znear, float zfar, int yolo, float* out,
+                     hipStream_t st, long long first, long long count);
 void launch_nchw_to_nhwc(const float* in, float* out, int n, int c, int hw, hipStream_t st);
 void launch_nhwc_to_nchw(const float* in, float* out, int n, int c, int hw, hipStream_t st);
 

@@ -338,15 +338,22 @@ void launch_yolo_aggregate(const float* raw, long long n, int k, int na, float* 
 //   yolo=0 (reference util.py:115-145,240-278): d = normalize((x-cx)/fx, -(y-cy)/fy, -1), dir = R d
 //   yolo=1 (reference util.py:808-876): d = Kinv [x+.49, y+.49, 1] (host passes Kinv entries in
 //   fx,fy,cx,cy as 1/fx, 1/fy, -cx/fx, -cy/fy), dir = Einv[:3,:3] d, not normalised.
-__global__ void gen_rays_kernel(const float* __restrict__ cam16, int b, int w, int h, float znear, float zfar,
-                                int yolo, float* __restrict__ out) {
+constexpr int GEN_RAYS_IMGS = 8;  // cameras per launch, passed by value in the kernel-argument segment (512 B):
+struct GenRaysCams {              // no device staging buffer, no copy, nothing to free or synchronise
+    float cam[GEN_RAYS_IMGS][16];
+};
+
+// Pixels [first, first + count) of the flattened (img, y, x) index space of images [img0, img0 + GEN_RAYS_IMGS).
+__global__ void gen_rays_kernel(const GenRaysCams cams, int img0, int w, int h, float znear, float zfar, int yolo,
+                                long long first, long long count, float* __restrict__ out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const long long p = first + i;
     const long long per = (long long)w * h;
-    if (i >= per * b) return;
-    const int img = (int)(i / per);
-    const int pix = (int)(i - img * per);
+    const int img = (int)(p / per);
+    const int pix = (int)(p - img * per);
     const int y = pix / w, x = pix - y * w;
-    const float* c = cam16 + img * 16;
+    const float* c = cams.cam[img - img0];
     float d0, d1, d2;
     if (!yolo) {
         d0 = ((float)x - c[14]) / c[12];
@@ -362,23 +369,28 @@ __global__ void gen_rays_kernel(const float* __restrict__ cam16, int b, int w, i
         d1 = c[13] * py + c[15];
         d2 = 1.0f;
     }
-    float* o = out + i * 8;
-    o[0] = c[9];
-    o[1] = c[10];
-    o[2] = c[11];
-    o[3] = c[0] * d0 + c[1] * d1 + c[2] * d2;
-    o[4] = c[3] * d0 + c[4] * d1 + c[5] * d2;
-    o[5] = c[6] * d0 + c[7] * d1 + c[8] * d2;
-    o[6] = znear;
-    o[7] = zfar;
+    float4* o = reinterpret_cast<float4*>(out + i * 8);  // hipMalloc / torch allocations: rows are 32-byte aligned
+    o[0] = make_float4(c[9], c[10], c[11], c[0] * d0 + c[1] * d1 + c[2] * d2);
+    o[1] = make_float4(c[3] * d0 + c[4] * d1 + c[5] * d2, c[6] * d0 + c[7] * d1 + c[8] * d2, znear, zfar);
 }
 
-void launch_gen_rays(const float* cam16, int b, int w, int h, float znear, float zfar, int yolo, float* out,
-                     hipStream_t st) {
-    const long long tot = (long long)b * w * h;
-    if (tot == 0) return;
-    hipLaunchKernelGGL(gen_rays_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, cam16, b, w, h, znear,
-                       zfar, yolo, out);
+// cam16_host: b x 16 floats (host).  Rays [first, first + count) of the (b, h, w) pixel grid -> out (count, 8).
+void launch_gen_rays(const float* cam16_host, int b, int w, int h, float znear, float zfar, int yolo, float* out,
+                     hipStream_t st, long long first, long long count) {
+    const long long per = (long long)w * h;
+    if (count <= 0) return;
+    for (int img0 = (int)(first / per); img0 < b && (long long)img0 * per < first + count; img0 += GEN_RAYS_IMGS) {
+        GenRaysCams cams;
+        const int nimg = (b - img0) < GEN_RAYS_IMGS ? (b - img0) : GEN_RAYS_IMGS;
+        for (int i = 0; i < GEN_RAYS_IMGS; ++i)
+            for (int k = 0; k < 16; ++k) cams.cam[i][k] = i < nimg ? cam16_host[(size_t)(img0 + i) * 16 + k] : 0.f;
+        const long long lo = first > (long long)img0 * per ? first : (long long)img0 * per;
+        const long long hi_img = (long long)(img0 + nimg) * per;
+        const long long hi = first + count < hi_img ? first + count : hi_img;
+        if (hi <= lo) continue;
+        hipLaunchKernelGGL(gen_rays_kernel, dim3((unsigned)((hi - lo + 255) / 256)), dim3(256), 0, st, cams, img0, w, h,
+                           znear, zfar, yolo, lo, hi - lo, out + (lo - first) * 8);
+    }
 }
 
 // ------------------------------------------------------------------ layout repack

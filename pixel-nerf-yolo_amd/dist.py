@@ -14,6 +14,13 @@ import torch
 import torch.distributed as dist
 
 
+def _world(group=None):
+    """(world_size, rank); (1, 0) when torch.distributed is not initialised (single-process use)."""
+    if not dist.is_available() or not dist.is_initialized():
+        return 1, 0
+    return dist.get_world_size(group), dist.get_rank(group)
+
+
 def shard_bounds(n, world_size, rank, multiple=64):
     """Contiguous [lo, hi) slice of n rays for `rank`; every shard except the last is a multiple
     of the MLP tile (64 samples) and all shards are padded to the same length for all_gather."""
@@ -26,21 +33,27 @@ def shard_bounds(n, world_size, rank, multiple=64):
 
 def gather_tiles(tile, n, per, group=None):
     """all_gather equal-sized (per, C) tiles and trim to n rows."""
-    world = dist.get_world_size(group)
+    world, _ = _world(group)
+    if world == 1:
+        return tile[:n]
     if tile.shape[0] < per:
         pad = torch.zeros(per - tile.shape[0], *tile.shape[1:], device=tile.device, dtype=tile.dtype)
         tile = torch.cat([tile, pad], 0)
-    out = torch.empty(world * per, *tile.shape[1:], device=tile.device, dtype=tile.dtype)
-    dist.all_gather_into_tensor(out, tile.contiguous(), group=group) if tile.is_cuda else \
-        dist.all_gather(list(out.chunk(world, 0)), tile.contiguous(), group=group)
-    return out[:n]
+    if tile.is_cuda and dist.get_backend(group) != "gloo":
+        out = torch.empty(world * per, *tile.shape[1:], device=tile.device, dtype=tile.dtype)
+        dist.all_gather_into_tensor(out, tile.contiguous(), group=group)      # RCCL, tensors stay on the GPU
+        return out[:n]
+    # gloo (CPU tests, and multi-process tests that share one GPU, where RCCL refuses duplicate devices)
+    host = tile.detach().cpu().contiguous()
+    out = torch.empty(world * per, *tile.shape[1:], dtype=tile.dtype)
+    dist.all_gather(list(out.chunk(world, 0)), host, group=group)
+    return out[:n].to(tile.device)
 
 
 def render_sharded(render_fn, rays, group=None):
     """rays (N, 8) identical on every rank -> (rgb (N,3), depth (N)) on every rank.
     render_fn(rays_slice (n_i, 8)) -> (rgb (n_i,3), depth (n_i))."""
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
+    world, rank = _world(group)
     n = rays.shape[0]
     lo, hi, per = shard_bounds(n, world, rank)
     if hi > lo:
@@ -50,3 +63,25 @@ def render_sharded(render_fn, rays, group=None):
         tile = torch.zeros(0, 4, device=rays.device, dtype=torch.float32)
     full = gather_tiles(tile, n, per, group)
     return full[:, :3], full[:, 3]
+
+
+def render_frame_sharded(render_fn, pose, width, height, focal, z_near, z_far, c=None, group=None, yolo=False,
+                         device=None):
+    """One target view rendered by all ranks: rank r GENERATES rays [lo_r, hi_r) of the (H, W) pixel grid on its own
+    device (no scatter), renders them with its persistent scene state and the frame is assembled with
+    one all-gather of (rays / G, 4) tiles.  pose (4, 4) as util.gen_rays takes it (util.gen_rays_yolo with yolo=True).
+    Returns (rgb (H, W, 3), depth (H, W)) on every rank."""
+    from .util import gen_rays_range
+    world, rank = _world(group)
+    n = int(width) * int(height)
+    lo, hi, per = shard_bounds(n, world, rank)
+    pose = torch.as_tensor(pose, dtype=torch.float32).reshape(1, 4, 4)
+    if hi > lo:
+        rays = gen_rays_range(pose, width, height, focal, z_near, z_far, lo, hi - lo, c=c, yolo=yolo, device=device)
+        rgb, depth = render_fn(rays)
+        tile = torch.cat([rgb, depth[:, None]], dim=1)
+    else:
+        dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        tile = torch.zeros(0, 4, device=dev, dtype=torch.float32)
+    full = gather_tiles(tile, n, per, group)
+    return full[:, :3].reshape(height, width, 3), full[:, 3].reshape(height, width)

@@ -60,6 +60,8 @@ SIGNATURES = {
     "pny_scene_latent_shape": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_int)] * 4),
     "pny_gen_rays": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, C.c_float, C.c_float,
                                C.c_int, C.c_void_p, C.c_void_p]),
+    "pny_gen_rays_range": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, C.c_float, C.c_float,
+                                     C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "pny_query": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "pny_render": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(RenderOpts), C.POINTER(RenderOut),
                              C.c_void_p]),
@@ -87,7 +89,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 3
+ABI_VERSION = 4
 PROJECTION = {"off": 0, "on": 1, "auto": 2}
 
 

@@ -461,39 +461,43 @@ class PixelNeRFNet(nn.Module):
         return out
 
     # ---------------------------------------------------------------- checkpoints
-    @staticmethod
-    def _ckpt_paths(args, opt_init):
-        """File layout of the reference (models.py:320-370): checkpoints/<name>/pixel_nerf_{latest,init}
-        plus a *_backup copy written before each overwrite."""
-        stem = "pixel_nerf_init" if opt_init else "pixel_nerf_latest"
-        backup = "pixel_nerf_init_backup" if opt_init else "pixel_nerf_backup"
-        root = osp.join(args.checkpoints_path, args.name)
-        return osp.join(root, stem), osp.join(root, backup)
-
     def load_weights(self, args, opt_init=False, strict=True, device=None):
-        """Same contract as reference models.py:320-349: load <checkpoints_path>/<name>/pixel_nerf_latest
-        (pixel_nerf_init with opt_init, only when resuming); warn -- do not fail -- when it is absent.
-        The file is a plain state_dict and is read with weights_only=True."""
+        """Same contract as reference models.py:320-349.  The file loaded is
+        <checkpoints_path>/<name>/pixel_nerf_init when ``opt_init or not args.resume`` and pixel_nerf_latest
+        otherwise; ``opt_init and not args.resume`` is a no-op that returns None (the reference's bare ``return``);
+        a missing file warns -- it does not fail -- unless opt_init.  The file is a plain state_dict and is read
+        with weights_only=True."""
         if opt_init and not args.resume:
-            return self
-        path, _ = self._ckpt_paths(args, opt_init)
-        if not osp.exists(path):
-            if not opt_init:
-                warnings.warn("WARNING: {} does not exist, not loaded!! Model will be re-initialized.".format(path))
-            return self
-        target = device if device is not None else self.mlp_coarse.lin_in.weight.device
-        print("Load", path)
-        state = torch.load(path, map_location=target, weights_only=True)
-        self.load_state_dict(state, strict=strict)
+            return
+        ckpt_name = "pixel_nerf_init" if opt_init or not args.resume else "pixel_nerf_latest"
+        model_path = "%s/%s/%s" % (args.checkpoints_path, args.name, ckpt_name)
+        if device is None:
+            device = self.mlp_coarse.lin_in.weight.device   # the reference asks self.poses.device: same module device
+        if osp.exists(model_path):
+            print("Load", model_path)
+            self.load_state_dict(torch.load(model_path, map_location=device, weights_only=True), strict=strict)
+        elif not opt_init:
+            warnings.warn(
+                ("WARNING: {} does not exist, not loaded!! Model will be re-initialized.\n"
+                 + "If you are trying to load a pretrained model, STOP since it's not in the right place. "
+                 + "If training, unless you are startin a new experiment, please remember to pass --resume."
+                 ).format(model_path))
         return self
 
-    def save_weights(self, args, opt_init=False):
-        """Same contract as reference models.py:351-370 (previous file kept as *_backup)."""
-        import shutil
-        path, backup = self._ckpt_paths(args, opt_init)
-        if osp.exists(path):
-            shutil.copyfile(path, backup)
-        torch.save(self.state_dict(), path)
+    def save_weights(self, args, opt_init=False, epochNum=""):
+        """Same contract as reference models.py:351-370: the current pixel_nerf_latest (pixel_nerf_init with
+        opt_init) is first copied to pixel_nerf_backup<epochNum> (pixel_nerf_init_backup); the state_dict is written
+        only when ``epochNum == ""`` -- the trainer's ``epochNum="_best"`` / ``str(epoch - 1)`` calls
+        (train/trainlib/trainer.py:246,251) only snapshot the file already on disk."""
+        from shutil import copyfile
+        ckpt_name = "pixel_nerf_init" if opt_init else "pixel_nerf_latest"
+        backup_name = "pixel_nerf_init_backup" if opt_init else "pixel_nerf_backup" + epochNum
+        ckpt_path = osp.join(args.checkpoints_path, args.name, ckpt_name)
+        ckpt_backup_path = osp.join(args.checkpoints_path, args.name, backup_name)
+        if osp.exists(ckpt_path):
+            copyfile(ckpt_path, ckpt_backup_path)
+        if epochNum == "":
+            torch.save(self.state_dict(), ckpt_path)
         return self
 
 

@@ -19,8 +19,10 @@ D_IN = 42  # 3 + 3*2*6 positional code + 3 view dirs (reference src/model/models
 
 
 def mlp_state(seed, d_latent=512, d_hidden=512, d_out=4, n_blocks=5, combine_layer=3,
-              d_in=D_IN, prefix=""):
-    """Dict name -> float32 array for one ResnetFC (reference src/model/resnetfc.py:66-132)."""
+              d_in=D_IN, prefix="", out_gain=1.0):
+    """Dict name -> float32 array for one ResnetFC (reference src/model/resnetfc.py:66-132).
+    out_gain scales lin_out.weight (same random numbers): YOLO-mode raw outputs are unbounded, and with gain 1 they
+    reach ~65, where an absolute 1e-4 is below fp32 resolution of the sum; 0.05 keeps them O(1)."""
     rs = np.random.RandomState(seed)
     sd = {}
 
@@ -30,7 +32,7 @@ def mlp_state(seed, d_latent=512, d_hidden=512, d_out=4, n_blocks=5, combine_lay
         sd[prefix + name + ".bias"] = (rs.standard_normal((fan_out,)) * 0.1).astype(np.float32)
 
     lin("lin_in", d_hidden, d_in)
-    lin("lin_out", d_out, d_hidden)
+    lin("lin_out", d_out, d_hidden, gain=out_gain)
     for i in range(n_blocks):
         lin("blocks.%d.fc_0" % i, d_hidden, d_hidden)
         lin("blocks.%d.fc_1" % i, d_hidden, d_hidden, gain=0.5)

@@ -54,6 +54,22 @@ def gen_rays(poses, width, height, focal, z_near, z_far, c=None, ndc=False, devi
     return out
 
 
+def gen_rays_range(poses, width, height, focal, z_near, z_far, first_ray, n_rays, c=None, yolo=False, device=None):
+    """Rays [first_ray, first_ray + n_rays) of the flattened (B, H, W) pixel grid of ``gen_rays`` (or
+    ``gen_rays_yolo`` with yolo=True) -> (n_rays, 8), bit-identical to the corresponding rows of the full call.
+    Not part of the reference's interface: it is how a rank of a ray-sharded render (dist.render_frame_sharded)
+    produces its own slice of a frame on its own device."""
+    dev = _device_of(poses, device)
+    B = poses.shape[0]
+    out = torch.empty(int(n_rays), 8, device=dev, dtype=torch.float32)
+    f = _pair(focal, "focal")
+    cc = _pair([width * 0.5, height * 0.5] if c is None else c, "c")
+    p = poses.detach().to("cpu", torch.float32).contiguous()
+    check(_lib.load().pny_gen_rays_range(ptr(p), B, int(width), int(height), f, cc, float(z_near), float(z_far),
+                                         int(bool(yolo)), int(first_ray), int(n_rays), ptr(out), stream_of(dev)))
+    return out
+
+
 def gen_rays_yolo(poses, width, height, focal, c, z_near, z_far, device=None):
     """
     :param poses (B, 4, 4) world-to-camera extrinsics;  focal (2), c (2)

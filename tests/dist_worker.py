@@ -27,3 +27,57 @@ def run(rank, world, port, n, q):
         torch.equal(depth, rays[:, 7] * 0.5)
     q.put((rank, bool(ok), tuple(rgb.shape)))
     dist.destroy_process_group()
+
+
+def run_render(rank, world, port, q):
+    """world_size ranks sharing cuda:0 (gloo: RCCL refuses duplicate devices) render ONE frame with
+    dist.render_frame_sharded through the HIP path: each rank generates and renders its own ray range with explicit
+    draws sliced from a common seeded set; the assembled frame must equal rank 0's single-call render bit for bit."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import pnyolo_pkg
+    pnyolo_pkg.load()
+    from pixel_nerf_yolo_amd import conf as pconf, dist as pdist, synth
+    from pixel_nerf_yolo_amd.model import make_model
+    from pixel_nerf_yolo_amd.render import NeRFRenderer
+    from pixel_nerf_yolo_amd.util import gen_rays
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    NS, H, W, kc, kf, kfd = 2, 40, 48, 16, 8, 4
+    net = make_model(pconf.default_mv()["model"]).eval()
+    for mlp, seed in ((net.mlp_coarse, 61), (net.mlp_fine, 62)):
+        mlp.load_state_dict({k: torch.from_numpy(v) for k, v in synth.mlp_state(seed).items()})
+    net = net.to(dev)
+    net.set_latent_projection("on")
+    src, tgt = synth.scene_cameras(NS)
+    focal, c = torch.tensor(50.0), torch.tensor([[W * 0.5, H * 0.5]])
+    net.encode(torch.zeros(1, NS, 3, H, W), torch.from_numpy(src)[None], focal, c=c,
+               latent=torch.from_numpy(synth.latent(63, NS, 512, H // 2, W // 2)))
+    n = H * W
+    rs = np.random.RandomState(64)
+    draws = dict(u_coarse=rs.rand(n, kc).astype(np.float32), u_fine=rs.rand(n, kf - kfd).astype(np.float32),
+                 u_fine2=rs.rand(n, kf - kfd).astype(np.float32), g_depth=rs.randn(n, kfd).astype(np.float32))
+    ren = NeRFRenderer(n_coarse=kc, n_fine=kf, n_fine_depth=kfd, white_bkgd=True).eval()
+    par = ren.bind_parallel(net, None, simple_output=True).eval()
+    lo, hi, per = pdist.shard_bounds(n, world, rank)
+
+    def render(rays):
+        ren.draws = {k: v[lo:hi] for k, v in draws.items()}
+        with torch.no_grad():
+            rgb, depth = par(rays[None])
+        return rgb[0], depth[0]
+
+    rgb, depth = pdist.render_frame_sharded(render, tgt, W, H, focal, 0.8, 1.8, c=c[0], device=dev)
+    ok, shape = True, tuple(rgb.shape)
+    if rank == 0:
+        rays = gen_rays(torch.from_numpy(tgt)[None], W, H, focal, 0.8, 1.8, c=c[0], device=dev).reshape(1, -1, 8)
+        ren.draws = draws
+        with torch.no_grad():
+            r1, d1 = par(rays)
+        ok = bool(torch.equal(r1[0].reshape(H, W, 3), rgb)) and bool(torch.equal(d1[0].reshape(H, W), depth))
+    q.put((rank, ok, shape, (lo, hi)))
+    dist.destroy_process_group()

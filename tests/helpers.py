@@ -12,19 +12,30 @@ def load_mlp(mlp, seed, d_latent, d_out):
     mlp.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
 
 
+def latent_dims(g):
+    """(channels, Hl, Wl) of a fixture_nerf golden; older fixtures are ResNet-34 sized (512, H/2, W/2)."""
+    H, W = int(g["H"]), int(g["W"])
+    if "d_latent" in g:
+        return int(g["d_latent"]), int(g["Hl"]), int(g["Wl"])
+    return 512, H // 2, W // 2
+
+
 def nerf_net(g, seed, device="cuda:0"):
     """PixelNeRFNet (HIP path) configured and seeded exactly like tools/make_golden.fixture_nerf."""
     c = pconf.default_mv()
     has_fine = int(g["Kf"]) > 0
     if not has_fine:
         c.d["model"]["mlp_fine"] = {"type": "empty"}
+    L, hl, wl = latent_dims(g)
+    if L != 512:
+        c.d["model"]["encoder"]["backbone"] = "custom"   # BASELINE configs 3-5: d_latent = 1792, latent supplied
     net = make_model(c["model"]).eval()
-    load_mlp(net.mlp_coarse, seed * 10 + 1, 512, 4)
+    load_mlp(net.mlp_coarse, seed * 10 + 1, L, 4)
     if has_fine:
-        load_mlp(net.mlp_fine, seed * 10 + 2, 512, 4)
+        load_mlp(net.mlp_fine, seed * 10 + 2, L, 4)
     net = net.to(device)
     ns, H, W = int(g["NS"]), int(g["H"]), int(g["W"])
-    lat = torch.from_numpy(synth.latent(seed * 10 + 3, ns, 512, H // 2, W // 2))
+    lat = torch.from_numpy(synth.latent(seed * 10 + 3, ns, L, hl, wl))
     images = torch.zeros(1, ns, 3, H, W)
     net.encode(images, torch.from_numpy(g["src_poses"])[None], torch.tensor(float(g["focal"])),
                c=torch.from_numpy(g["c"])[None], latent=lat)
@@ -34,9 +45,10 @@ def nerf_net(g, seed, device="cuda:0"):
 def oracle_scene(g, seed):
     import pnyolo_oracle as orc
     ns, H, W = int(g["NS"]), int(g["H"]), int(g["W"])
-    mc = synth.mlp_state(seed * 10 + 1)
-    mf = synth.mlp_state(seed * 10 + 2) if int(g["Kf"]) > 0 else None
-    lat = synth.latent(seed * 10 + 3, ns, 512, H // 2, W // 2)
+    L, hl, wl = latent_dims(g)
+    mc = synth.mlp_state(seed * 10 + 1, d_latent=L)
+    mf = synth.mlp_state(seed * 10 + 2, d_latent=L) if int(g["Kf"]) > 0 else None
+    lat = synth.latent(seed * 10 + 3, ns, L, hl, wl)
     return orc.Scene(mc, mf, lat, g["src_poses"], g["focal"], g["c"][None], W, H)
 
 
@@ -44,3 +56,70 @@ def maxabs(a, b):
     a = torch.as_tensor(np.asarray(a.detach().cpu() if torch.is_tensor(a) else a), dtype=torch.float32)
     b = torch.as_tensor(np.asarray(b.detach().cpu() if torch.is_tensor(b) else b), dtype=torch.float32)
     return float((a - b).abs().max())
+
+
+DEV = "cuda:0"
+
+
+def dt(x, device=DEV):
+    return torch.as_tensor(np.asarray(x), dtype=torch.float32, device=device).contiguous()
+
+
+def render_debug(ren, net, rays, draws, kc, kt, device=DEV):
+    """Render with explicit draws and capture the per-sample / z buffers through the ABI."""
+    n = rays.shape[0]
+    dbg = {"z_coarse": torch.empty(1, n, kc, device=device), "sample_coarse": torch.empty(1, n, kc, 4, device=device)}
+    if kt > kc:
+        dbg["z_fine"] = torch.empty(1, n, kt, device=device)
+        dbg["sample_fine"] = torch.empty(1, n, kt, 4, device=device)
+    ren._debug_out = dbg
+    ren.draws = draws
+    with torch.no_grad():
+        out = ren(net, dt(rays, device)[None], want_weights=True)
+    torch.cuda.synchronize()
+    ren._debug_out = None
+    return out, dbg
+
+
+def fine_flip_rays(z_hip, z_ref, weights_ref, u_fine):
+    """Rays whose sorted fine depths differ from the reference's; each must be explained by a draw that sits within
+    1e-5 of a cdf edge (importance sampling is discontinuous in the coarse weights)."""
+    bad = ((z_hip - z_ref).abs().max(dim=1)[0] > 1e-6).nonzero().flatten().tolist()
+    w = weights_ref + 1e-5
+    cdf = torch.cumsum(w / w.sum(-1, keepdim=True), -1)
+    for r in bad:
+        margin = (cdf[r][None, :] - torch.as_tensor(u_fine[r])[:, None]).abs().min()
+        assert float(margin) < 1e-5, "ray %d differs without a near-edge draw (margin %.2e)" % (r, float(margin))
+    return bad
+
+
+def check_against_nerf_golden(g, out, dbg, tol, max_flips=2):
+    """HIP render (out, dbg from render_debug) against a fixture_nerf-style golden: bit-exact coarse depths, per-sample
+    rgb / sigma, weights and pixels within `tol` ABSOLUTE; fine pass on the rays whose bins did not flip."""
+    import pnyolo_oracle as orc
+    n, kc, kf, kfd = g["rays"].shape[0], int(g["Kc"]), int(g["Kf"]), int(g["Kfd"])
+    if "z_coarse" in g:
+        assert maxabs(dbg["z_coarse"][0], g["z_coarse"]) == 0.0
+    assert maxabs(dbg["sample_coarse"][0].reshape(-1, 4), g["coarse_out"]) < tol
+    for k in ("rgb", "depth", "weights"):
+        assert maxabs(out["coarse"][k][0], g["coarse_" + k]) < tol, k
+    if kf == 0:
+        return []
+    rays = torch.from_numpy(g["rays"])
+    zc = orc.sample_coarse(rays, kc, g["u_coarse"])
+    samps = [zc]
+    if kf - kfd > 0:
+        samps.append(orc.sample_fine(rays, torch.from_numpy(g["coarse_weights"]), g["u_fine"], g["u_fine2"], kc))
+    if kfd > 0:
+        samps.append(orc.sample_fine_depth(rays, torch.from_numpy(g["coarse_depth"]), g["g_depth"], 0.01))
+    z_ref, _ = torch.sort(torch.cat(samps, -1), -1)
+    bad = fine_flip_rays(dbg["z_fine"][0].cpu(), z_ref, torch.from_numpy(g["coarse_weights"]), g["u_fine"])
+    assert len(bad) <= max_flips, bad
+    good = torch.ones(n, dtype=torch.bool)
+    good[bad] = False
+    kt = kc + kf
+    assert maxabs(dbg["sample_fine"][0].cpu()[good].reshape(-1, 4), g["fine_out"].reshape(n, kt, 4)[good].reshape(-1, 4)) < tol
+    for k in ("rgb", "depth", "weights"):
+        assert maxabs(out["fine"][k][0].cpu()[good], g["fine_" + k][good]) < tol, k
+    assert maxabs(out["fine"]["rgb"][0], g["fine_rgb"]) < 2e-2   # a moved sample changes the quadrature, not the scene
+    return bad

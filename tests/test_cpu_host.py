@@ -37,7 +37,7 @@ def test_abi_exports_every_declared_symbol(built_lib):
     assert declared == set(plib.SIGNATURES.keys()), declared ^ set(plib.SIGNATURES.keys())
     for name in declared:
         assert hasattr(built_lib, name)
-    assert built_lib.pny_version() == 3
+    assert built_lib.pny_version() == plib.ABI_VERSION == 4
 
 
 def test_no_gpu_is_loud(built_lib):
@@ -221,3 +221,54 @@ def test_bench_json_contract_fields():
         assert k in d
     assert d["unit"] == "rays/s" and d["config"]["workload"].startswith("C2")
     assert abs(d["flop_per_ray"] - 2.6218e9) / 2.6218e9 < 1e-3
+
+
+def test_checkpoint_contract_matches_reference(tmp_path):
+    """load_weights / save_weights against tests/golden/ckpt.json, which tools/make_golden.py captured by driving the
+    reference's PixelNeRFNet (models.py:320-370) through the same sequence: which file each (resume, opt_init)
+    combination loads, the bare `return` (None) for opt_init without resume, the warning for a missing file, and the
+    trainer's epochNum calls (trainer.py:246-256) that only snapshot the file on disk."""
+    import json
+    import shutil
+    import warnings
+    from types import SimpleNamespace
+
+    rec = json.load(open(os.path.join(ROOT, "tests", "golden", "ckpt.json")))
+    conf = pconf.default_mv()["model"]
+
+    def fresh(marker):
+        net = make_model(conf)
+        with torch.no_grad():
+            net.mlp_coarse.lin_out.bias.fill_(marker)
+        return net
+
+    def marker_of(sd):
+        return float(sd["mlp_coarse.lin_out.bias"][0])
+
+    root = tmp_path / "exp"
+    last_files = None
+    for case in rec["load"]:
+        if case["files"] != last_files:
+            shutil.rmtree(root, ignore_errors=True)
+            root.mkdir()
+            for fn, mk in (("pixel_nerf_init", 1.0), ("pixel_nerf_latest", 2.0)):
+                if fn in case["files"]:
+                    torch.save(fresh(mk).state_dict(), str(root / fn))
+            last_files = case["files"]
+        args = SimpleNamespace(checkpoints_path=str(tmp_path), name="exp", resume=case["resume"])
+        net = fresh(0.0)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            ret = net.load_weights(args, opt_init=case["opt_init"])
+        got = {"marker_after": marker_of(net.state_dict()), "returns_self": ret is net, "returns_none": ret is None,
+               "warned": any("does not exist" in str(x.message) for x in w)}
+        assert got == {k: case[k] for k in got}, (case, got)
+    shutil.rmtree(root, ignore_errors=True)
+    root.mkdir()
+    args = SimpleNamespace(checkpoints_path=str(tmp_path), name="exp", resume=True)
+    for step in rec["save"]:
+        ret = fresh(step["marker"]).save_weights(args, **step["kwargs"])
+        assert (ret is not None) == step["returns_self"]
+        files = {fn: marker_of(torch.load(str(root / fn), map_location="cpu", weights_only=True))
+                 for fn in sorted(os.listdir(root))}
+        assert files == step["files"], (step, files)

@@ -20,9 +20,11 @@ def maxabs(a, b):
 
 def nerf_scene(g, seed):
     ns, H, W = int(g["NS"]), int(g["H"]), int(g["W"])
-    mc = synth.mlp_state(seed * 10 + 1)
-    mf = synth.mlp_state(seed * 10 + 2) if int(g["Kf"]) > 0 else None
-    lat = synth.latent(seed * 10 + 3, ns, 512, H // 2, W // 2)
+    L = int(g["d_latent"]) if "d_latent" in g else 512
+    hl, wl = (int(g["Hl"]), int(g["Wl"])) if "Hl" in g else (H // 2, W // 2)
+    mc = synth.mlp_state(seed * 10 + 1, d_latent=L)
+    mf = synth.mlp_state(seed * 10 + 2, d_latent=L) if int(g["Kf"]) > 0 else None
+    lat = synth.latent(seed * 10 + 3, ns, L, hl, wl)
     return orc.Scene(mc, mf, lat, g["src_poses"], g["focal"], g["c"][None], W, H)
 
 
@@ -93,6 +95,45 @@ def test_render_c2(golden):
     assert maxabs(r["fine"]["depth"], g["fine_depth"]) < 5e-6
 
 
+def test_render_c3_c4(golden):
+    """BASELINE configs 3 and 4 at reduced ray counts: L = 1792 conditioning (backbone = custom in the reference's
+    config, latent supplied), NeRF renderer with 64 + 32 (16) and 128 + 64 (32) samples, 400 x 400 geometry for C4."""
+    for name, seed, (kc, kf, kfd) in (("nerf_c3", 31, (64, 32, 16)), ("nerf_c4", 37, (128, 64, 32))):
+        g = golden(name)
+        assert int(g["d_latent"]) == 1792 and (int(g["Kc"]), int(g["Kf"]), int(g["Kfd"])) == (kc, kf, kfd)
+        sc = nerf_scene(g, seed)
+        r = orc.render(sc, g["rays"], kc, kf, kfd, g["u_coarse"], g["u_fine"], g["u_fine2"], g["g_depth"], chunk=5000)
+        assert maxabs(r["coarse"]["z"], g["z_coarse"]) == 0.0
+        assert maxabs(r["coarse"]["out"].reshape(-1, 4), g["coarse_out"]) < 2e-5, name
+        assert maxabs(r["coarse"]["rgb"], g["coarse_rgb"]) < 2e-6, name
+        assert maxabs(r["coarse"]["weights"], g["coarse_weights"]) < 2e-6, name
+        assert maxabs(r["fine"]["out"].reshape(-1, 4), g["fine_out"]) < 5e-5, name
+        assert maxabs(r["fine"]["weights"], g["fine_weights"]) < 5e-6, name
+        assert maxabs(r["fine"]["rgb"], g["fine_rgb"]) < 5e-6, name
+        assert maxabs(r["fine"]["depth"], g["fine_depth"]) < 5e-6, name
+        out = orc.query(sc, g["probe_xyz"], g["probe_viewdirs"], coarse=False)
+        assert maxabs(out, g["probe_out_fine"]) < 2e-5, name
+
+
+def test_encoder_to_render(golden):
+    """tests/golden/enc_render.npz: the reference's SpatialEncoder.forward -> encode -> NeRFRenderer.forward with
+    nothing bypassed.  The oracle's trunk + render against it: latent, per-sample rgb / sigma and pixels."""
+    g = golden("enc_render")
+    seed, ns, H, W = int(g["seed"]), int(g["NS"]), int(g["H"]), int(g["W"])
+    esd = synth.resnet34_state(seed * 10 + 4, residual_gain=float(g["residual_gain"]))
+    lat, _ = orc.spatial_encoder(esd, synth.images(seed * 10 + 5, ns, H, W))
+    assert tuple(lat.shape) == tuple(int(v) for v in g["latent_shape"])
+    assert maxabs(lat.reshape(-1)[torch.from_numpy(g["latent_idx"])], g["latent_val"]) < 2e-5
+    sc = orc.Scene(synth.mlp_state(seed * 10 + 1), synth.mlp_state(seed * 10 + 2), lat, g["src_poses"], g["focal"],
+                   g["c"][None], W, H)
+    r = orc.render(sc, g["rays"], 64, 32, 16, g["u_coarse"], g["u_fine"], g["u_fine2"], g["g_depth"], chunk=3000)
+    assert maxabs(r["coarse"]["out"].reshape(-1, 4), g["coarse_out"]) < 5e-5
+    assert maxabs(r["coarse"]["rgb"], g["coarse_rgb"]) < 5e-6
+    assert maxabs(r["fine"]["out"].reshape(-1, 4), g["fine_out"]) < 1e-4
+    assert maxabs(r["fine"]["rgb"], g["fine_rgb"]) < 1e-5
+    assert maxabs(r["fine"]["depth"], g["fine_depth"]) < 1e-5
+
+
 def test_stages_from_golden_inputs(golden):
     """Each stage fed the reference's own intermediate values -> bitwise / 1-ulp agreement."""
     g = golden("nerf_c2")
@@ -119,6 +160,28 @@ def test_yolo_render(golden):
     assert maxabs(r["raw"].reshape(-1, 21), g["raw_out"]) < 2e-5 * max(1.0, scale)
     assert maxabs(r["out"], g["yolo_out"]) < 5e-5
     assert maxabs(orc.yolo_aggregate(t(g["raw_out"]).reshape(42, 128, 21)), g["yolo_out"]) < 1e-6
+
+
+def test_yolo_render_unit_magnitude(golden):
+    """Companion of yolo_c3 with lin_out scaled by 0.05: raw outputs are O(1), so the comparison is absolute."""
+    g = golden("yolo_c3_unit")
+    seed = int(g["seed"])
+    mc = synth.mlp_state(seed * 10 + 1, d_latent=1792, d_out=21, out_gain=float(g["out_gain"]))
+    lat = synth.latent(seed * 10 + 3, 3, 1792, 16, 16)
+    sc = orc.Scene(mc, None, lat, g["src_w2c"], g["focal"][None], g["c"][None], 128, 128, yolo=True)
+    r = orc.yolo_render(sc, g["rays"], 128, g["u_coarse"], chunk=128)
+    assert float(np.abs(g["raw_out"]).max()) < 5.0
+    assert maxabs(r["raw"].reshape(-1, 21), g["raw_out"]) < 1e-5
+    assert maxabs(r["out"], g["yolo_out"]) < 1e-5
+
+
+def test_encoder_unit_magnitude(golden):
+    """Companion of `encoder` on the well-conditioned trunk (residual_gain = 0.25): absolute comparison."""
+    g = golden("encoder_unit")
+    seed = int(g["seed"])
+    sd = synth.resnet34_state(seed * 10 + 5, prefix="encoder.model.", residual_gain=float(g["residual_gain"]))
+    lat, _ = orc.spatial_encoder(sd, synth.images(seed * 10 + 6, int(g["NS"]), int(g["H"]), int(g["W"])))
+    assert maxabs(lat, g["latent"]) < 2e-5
 
 
 def test_encoder(golden):

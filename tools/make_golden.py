@@ -243,8 +243,12 @@ def np_(t):
 
 
 # --------------------------------------------------------------------------- fixtures
-def fixture_nerf(name, H, NS, Kc, Kf, Kfd, n_rays, seed, ebs):
+def fixture_nerf(name, H, NS, Kc, Kf, Kfd, n_rays, seed, ebs, d_latent=512, lat_hw=None):
+    """d_latent = 1792 builds the reference model with backbone = "custom" (BASELINE configs 3-5: the YOLOv7 encoder's
+    channel count, custom_encoder.py:22) and the NeRF renderer / d_out = 4 MLPs; the backbone itself is outside the
+    tree, so a dummy module with dims = [1792] is patched in and the latent (lat_hw, default H/2 x W/2) is an input."""
     import util
+    import model.encoder as enc_mod
     from model import make_model
     from render import NeRFRenderer
 
@@ -253,15 +257,24 @@ def fixture_nerf(name, H, NS, Kc, Kf, Kfd, n_rays, seed, ebs):
     focal = torch.tensor(131.25 * H / 128.0)
     c_img = torch.tensor([W * 0.5, H * 0.5])
     z_near, z_far = 0.8, 1.8
-    conf = model_conf(has_fine=Kf > 0)
+    if d_latent == 512:
+        conf = model_conf(has_fine=Kf > 0)
+    else:
+        class DummyYolo(nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.dims = [d_latent]
+
+        enc_mod.YOLOEncoder = DummyYolo
+        conf = model_conf(backbone="custom", has_fine=Kf > 0)
     net = make_model(conf).eval()
-    load_mlp(net.mlp_coarse, seed * 10 + 1, 512, 4)
+    load_mlp(net.mlp_coarse, seed * 10 + 1, d_latent, 4)
     if Kf > 0:
-        load_mlp(net.mlp_fine, seed * 10 + 2, 512, 4)
+        load_mlp(net.mlp_fine, seed * 10 + 2, d_latent, 4)
 
     src_poses, tgt_pose = synth.scene_cameras(NS)
-    Hl, Wl = H // 2, W // 2
-    lat = synth.latent(seed * 10 + 3, NS, 512, Hl, Wl)
+    Hl, Wl = lat_hw if lat_hw is not None else (H // 2, W // 2)
+    lat = synth.latent(seed * 10 + 3, NS, d_latent, Hl, Wl)
     images = torch.zeros(1, NS, 3, H, W)
 
     # encode(): run the reference's pose / intrinsics handling, but bypass the conv trunk by
@@ -289,7 +302,7 @@ def fixture_nerf(name, H, NS, Kc, Kf, Kfd, n_rays, seed, ebs):
         out = renderer(net, rays[None], want_weights=True)
 
     d = {
-        "H": H, "W": W, "NS": NS, "Kc": Kc, "Kf": Kf, "Kfd": Kfd, "seed": seed,
+        "H": H, "W": W, "NS": NS, "Kc": Kc, "Kf": Kf, "Kfd": Kfd, "seed": seed, "d_latent": d_latent, "Hl": Hl, "Wl": Wl,
         "focal": np_(focal), "c": np_(c_img), "z_near": z_near, "z_far": z_far,
         "src_poses": src_poses, "tgt_pose": tgt_pose, "rays": np_(rays), "ray_idx": ray_idx,
         "all_rays_corner": np_(all_rays[:2, :3]),
@@ -343,7 +356,7 @@ def fixture_nerf(name, H, NS, Kc, Kf, Kfd, n_rays, seed, ebs):
     print("wrote", name, {k: getattr(v, "shape", v) for k, v in d.items() if k in ("rays", "coarse_out", "fine_rgb")})
 
 
-def fixture_yolo(name, seed, n_rays=40, K=128, ebs=128):
+def fixture_yolo(name, seed, n_rays=40, K=128, ebs=128, out_gain=1.0):
     """YOLO mode: gen_rays_yolo, world->cam poses used as given, raw 21-vector MLP output,
     YoloRenderer aggregation (reference yolo.py:37-114, models.py:119-120,222-224,254-264)."""
     import util
@@ -361,7 +374,8 @@ def fixture_yolo(name, seed, n_rays=40, K=128, ebs=128):
     enc_mod.YOLOEncoder = DummyYolo
     conf = model_conf(backbone="custom", yolo=True, has_fine=False)
     net = make_model(conf).eval()
-    load_mlp(net.mlp_coarse, seed * 10 + 1, 1792, 21)
+    sd = synth.mlp_state(seed * 10 + 1, d_latent=1792, d_out=21, out_gain=out_gain)
+    net.mlp_coarse.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     NS, H, W = 3, 128, 128
     Hl, Wl = 16, 16
     lat = synth.latent(seed * 10 + 3, NS, 1792, Hl, Wl)
@@ -395,7 +409,7 @@ def fixture_yolo(name, seed, n_rays=40, K=128, ebs=128):
     with torch.no_grad(), Recorder() as rec:
         out = renderer(rays[None])
     d = {
-        "seed": seed, "NS": NS, "H": H, "W": W, "K": K, "Hl": Hl, "Wl": Wl,
+        "seed": seed, "NS": NS, "H": H, "W": W, "K": K, "Hl": Hl, "Wl": Wl, "out_gain": out_gain,
         "focal": np_(focal), "c": np_(c_img), "src_w2c": src_w2c, "tgt_w2c": tgt_w2c,
         "Wc": Wc, "Hc": Hc, "rays_all": np_(rays_all[0]), "rays": np_(rays),
         "u_coarse": np_(rec.draws[0][1]),
@@ -407,7 +421,7 @@ def fixture_yolo(name, seed, n_rays=40, K=128, ebs=128):
     print("wrote", name, d["raw_out"].shape, d["yolo_out"].shape)
 
 
-def fixture_encoder(name, seed, NS=2, H=64, W=48, use_first_pool=True):
+def fixture_encoder(name, seed, NS=2, H=64, W=48, use_first_pool=True, residual_gain=1.0):
     """SpatialEncoder.forward (reference encoder.py:110-173) over the ResNet-34 skeleton with
     seeded random weights, eval-mode batch norm."""
     from model.encoder import SpatialEncoder
@@ -415,7 +429,7 @@ def fixture_encoder(name, seed, NS=2, H=64, W=48, use_first_pool=True):
     torch.manual_seed(seed)
     enc = SpatialEncoder(backbone="resnet34", pretrained=False, num_layers=4, index_padding="zeros",
                          use_first_pool=use_first_pool).eval()
-    sd = synth.resnet34_state(seed * 10 + 5, prefix="model.")
+    sd = synth.resnet34_state(seed * 10 + 5, prefix="model.", residual_gain=residual_gain)
     missing = enc.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
     assert all(k.startswith(("model.layer4", "model.fc")) or "num_batches_tracked" in k for k in missing.missing_keys), missing
     img = synth.images(seed * 10 + 6, NS, H, W)
@@ -427,7 +441,8 @@ def fixture_encoder(name, seed, NS=2, H=64, W=48, use_first_pool=True):
     uv = rs.uniform(-8.0, max(H, W) + 8.0, size=(NS, 50, 2)).astype(np.float32)
     with torch.no_grad():
         samp = enc.index(torch.from_numpy(uv), None, torch.tensor([float(W), float(H)]))
-    d = {"seed": seed, "NS": NS, "H": H, "W": W, "latent": np_(lat), "latent_scaling": np_(enc.latent_scaling),
+    d = {"seed": seed, "NS": NS, "H": H, "W": W, "residual_gain": residual_gain, "latent": np_(lat),
+         "latent_scaling": np_(enc.latent_scaling),
          "level1": levels[1][:, :8], "level3": levels[3][:, :8], "uv": uv, "index_out": np_(samp)}
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
     print("wrote", name, d["latent"].shape)
@@ -735,9 +750,143 @@ def fixture_grads(name, seed=19):
     print("wrote", name, "loss %.6f" % float(loss), len(names), "parameter gradients + latent")
 
 
+def fixture_enc_render(name, seed=23, H=128, NS=3, Kc=64, Kf=32, Kfd=16, n_rays=100, ebs=3000):
+    """End to end, nothing bypassed: the reference's own SpatialEncoder.forward (encoder.py:110-173, ResNet-34 skeleton,
+    eval-mode batch norm) on seeded images -> PixelNeRFNet.encode -> NeRFRenderer.forward (nerf.py:257-309) at the C2
+    shape.  The trunk is the well-conditioned one bench.py uses (synth.resnet34_state(residual_gain=0.25): latent O(1)
+    like a trained trunk's), so RGB / sigma are comparable at an ABSOLUTE 1e-4.  Images and weights are regenerated
+    from their seeds by the test; the latent is stored as a seeded sample of entries + its max |.|."""
+    import util
+    from model import make_model
+    from render import NeRFRenderer
+
+    torch.manual_seed(seed)
+    W = H
+    focal = torch.tensor(131.25 * H / 128.0)
+    c_img = torch.tensor([W * 0.5, H * 0.5])
+    z_near, z_far = 0.8, 1.8
+    net = make_model(model_conf(has_fine=True)).eval()
+    load_mlp(net.mlp_coarse, seed * 10 + 1, 512, 4)
+    load_mlp(net.mlp_fine, seed * 10 + 2, 512, 4)
+    esd = synth.resnet34_state(seed * 10 + 4, prefix="encoder.model.", residual_gain=0.25)
+    res = net.load_state_dict({k: torch.from_numpy(v) for k, v in esd.items()}, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys
+    assert all(k.startswith(("encoder.model.layer4", "encoder.model.fc", "mlp_", "code.")) or "num_batches_tracked" in k
+               for k in res.missing_keys), res.missing_keys
+    src_poses, tgt_pose = synth.scene_cameras(NS)
+    images = torch.from_numpy(synth.images(seed * 10 + 5, NS, H, W))
+    with torch.no_grad():
+        net.encode(images[None], torch.from_numpy(src_poses)[None], focal, c=c_img[None])
+    lat = net.encoder.latent.detach()
+    all_rays = util.gen_rays(torch.from_numpy(tgt_pose)[None], W, H, focal, z_near, z_far, c=c_img)[0]
+    rays, ray_idx = pick_rays(all_rays, n_rays, seed)
+    renderer = NeRFRenderer(n_coarse=Kc, n_fine=Kf, n_fine_depth=Kfd, depth_std=0.01, white_bkgd=True,
+                            eval_batch_size=ebs).eval()
+    calls = record_model_calls(net)
+    with torch.no_grad(), Recorder() as rec:
+        out = renderer(net, rays[None], want_weights=True)
+    draws = rec.draws
+    assert [k for k, _ in draws] == ["rand_like", "rand", "rand_like", "randn_like"]
+    rs = np.random.RandomState(seed)
+    lat_idx = rs.choice(lat.numel(), size=20000, replace=False).astype(np.int64)
+    d = {
+        "H": H, "W": W, "NS": NS, "Kc": Kc, "Kf": Kf, "Kfd": Kfd, "seed": seed, "residual_gain": 0.25,
+        "focal": np_(focal), "c": np_(c_img), "z_near": z_near, "z_far": z_far, "src_poses": src_poses,
+        "tgt_pose": tgt_pose, "rays": np_(rays), "ray_idx": ray_idx,
+        "latent_shape": np.array(lat.shape), "latent_idx": lat_idx, "latent_val": np_(lat.reshape(-1)[torch.from_numpy(lat_idx)]),
+        "latent_absmax": float(lat.abs().max()), "latent_std": float(lat.std()),
+        "u_coarse": np_(draws[0][1]), "u_fine": np_(draws[1][1]), "u_fine2": np_(draws[2][1]), "g_depth": np_(draws[3][1]),
+        "coarse_out": np_(torch.cat([o for (cf, o) in calls if cf], dim=1)[0]),
+        "fine_out": np_(torch.cat([o for (cf, o) in calls if not cf], dim=1)[0]),
+    }
+    for part in ("coarse", "fine"):
+        for k in ("rgb", "depth", "weights"):
+            d["%s_%s" % (part, k)] = np_(out[part][k][0])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print("wrote", name, "latent absmax %.3f std %.3f" % (d["latent_absmax"], d["latent_std"]),
+          "sigma max %.2f" % float(d["fine_out"][:, 3].max()))
+
+
+def fixture_ckpt(name, seed=29):
+    """PixelNeRFNet.load_weights / save_weights (reference models.py:320-370) driven through the (resume, opt_init)
+    combinations and the trainer's epochNum calls (train/trainlib/trainer.py:246-256) with real files in a scratch
+    directory.  Checkpoints are told apart by a marker (every entry of mlp_coarse.lin_out.bias).  Stored as JSON."""
+    import json
+    import shutil
+    import tempfile
+    import warnings
+    from types import SimpleNamespace
+    from model import make_model
+
+    torch.manual_seed(seed)
+
+    def fresh(marker):
+        net = make_model(model_conf(has_fine=True))
+        with torch.no_grad():
+            net.mlp_coarse.lin_out.bias.fill_(marker)
+        return net
+
+    def marker_of(obj):
+        sd = obj if isinstance(obj, dict) else obj.state_dict()
+        return float(sd["mlp_coarse.lin_out.bias"][0])
+
+    def listing(root):
+        out = {}
+        for fn in sorted(os.listdir(root)):
+            out[fn] = marker_of(torch.load(os.path.join(root, fn), map_location="cpu"))
+        return out
+
+    tmp = tempfile.mkdtemp(prefix="pny_ckpt_")
+    rec = {"load": [], "save": []}
+    try:
+        for files in (("pixel_nerf_init", "pixel_nerf_latest"), ("pixel_nerf_latest",), ("pixel_nerf_init",), ()):
+            root = os.path.join(tmp, "exp")
+            shutil.rmtree(root, ignore_errors=True)
+            os.makedirs(root)
+            for fn, mk in (("pixel_nerf_init", 1.0), ("pixel_nerf_latest", 2.0)):
+                if fn in files:
+                    torch.save(fresh(mk).state_dict(), os.path.join(root, fn))
+            for resume in (False, True):
+                for opt_init in (False, True):
+                    args = SimpleNamespace(checkpoints_path=tmp, name="exp", resume=resume)
+                    net = fresh(0.0)
+                    with warnings.catch_warnings(record=True) as w:
+                        warnings.simplefilter("always")
+                        ret = net.load_weights(args, opt_init=opt_init)
+                    rec["load"].append({"files": list(files), "resume": resume, "opt_init": opt_init,
+                                        "marker_after": marker_of(net), "returns_self": ret is net,
+                                        "returns_none": ret is None, "warned": len(w) > 0})
+        # save_weights: the trainer's sequence (best snapshot, per-epoch snapshot, plain save), then opt_init
+        root = os.path.join(tmp, "exp")
+        shutil.rmtree(root, ignore_errors=True)
+        os.makedirs(root)
+        args = SimpleNamespace(checkpoints_path=tmp, name="exp", resume=True)
+        steps = [(3.0, dict(epochNum="_best")), (4.0, dict()), (5.0, dict(epochNum="_best")), (6.0, dict(epochNum="7")),
+                 (7.0, dict()), (8.0, dict(opt_init=True)), (9.0, dict(opt_init=True)), (10.0, dict(opt_init=True, epochNum="x"))]
+        for mk, kw in steps:
+            ret = fresh(mk).save_weights(args, **kw)
+            rec["save"].append({"marker": mk, "kwargs": kw, "returns_self": ret is not None, "files": listing(root)})
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    with open(os.path.join(OUT, name + ".json"), "w") as fh:
+        json.dump(rec, fh, indent=1, sort_keys=True)
+    print("wrote", name, len(rec["load"]), "load cases,", len(rec["save"]), "save steps")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_shims()
+    only = set(sys.argv[1:])   # optional: fixture names to (re)generate; default all
+    if only:
+        g = globals()
+        for fn_name in [k for k in g if k.startswith("fixture_")]:
+            f = g[fn_name]
+
+            def gated(name, *a, _f=f, **k):
+                if name in only:
+                    return _f(name, *a, **k)
+
+            g[fn_name] = gated
     fixture_rays("rays")
     # C1-like: single view, coarse only (BASELINE config 1 at reduced ray count)
     fixture_nerf("nerf_c1", H=64, NS=1, Kc=32, Kf=0, Kfd=0, n_rays=80, seed=1, ebs=1000)
@@ -752,6 +901,14 @@ def main():
     fixture_sched("sched")
     fixture_mlp_shapes("mlp_shapes")
     fixture_grads("nerf_grads")
+    # BASELINE configs 3 and 4 at reduced ray counts: L = 1792 conditioning, NeRF renderer, d_out = 4
+    fixture_nerf("nerf_c3", H=128, NS=3, Kc=64, Kf=32, Kfd=16, n_rays=100, seed=31, ebs=3000, d_latent=1792, lat_hw=(16, 16))
+    fixture_nerf("nerf_c4", H=400, NS=3, Kc=128, Kf=64, Kfd=32, n_rays=64, seed=37, ebs=5000, d_latent=1792, lat_hw=(50, 50))
+    # companions with O(1) magnitudes (absolute 1e-4 is meaningful): YOLO raw outputs, encoder latent
+    fixture_yolo("yolo_c3_unit", seed=41, out_gain=0.05)
+    fixture_encoder("encoder_unit", seed=43, NS=1, H=64, W=48, residual_gain=0.25)
+    fixture_enc_render("enc_render")
+    fixture_ckpt("ckpt")
 
 
 if __name__ == "__main__":
