@@ -114,6 +114,10 @@ def main():
                     help="c2 = BASELINE.json configs[1] (default, the bench line); c3/c4/c5 = configs[2..4]")
     ap.add_argument("--no-reference-order", action="store_true", help="skip the --projection off leg of the N=1 line")
     ap.add_argument("--describe", action="store_true", help="print the workload description and exit (no GPU)")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="multi-rank REHEARSAL on a one-GPU box: every rank uses device 0 and the exchange goes over gloo "
+                         "(RCCL refuses duplicate devices); checks the launch / sharding / gather mechanics, the line is "
+                         "marked rehearsal and is not a measurement")
     args = ap.parse_args()
     wl = args.workload
     side, d_latent, lat_side, KC, KF, KFD, scaling, wl_text = WORKLOADS[wl]
@@ -144,10 +148,15 @@ def main():
     if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path for the product)"
+    if args.rehearse_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     n_ranks_seen = dist.get_world_size() if dist.is_initialized() else 1
 
     H = W = side
@@ -216,6 +225,14 @@ def main():
     gathered = torch.empty(world * per, 4, device=dev) if exchange else None
     tile = torch.zeros(per, 4, device=dev) if exchange else None
 
+    def all_gather_tiles():
+        if args.rehearse_one_gpu:   # gloo has no device all-gather: stage through the host (rehearsal only)
+            host = torch.empty(world * per, 4)
+            dist.all_gather(list(host.chunk(world, 0)), tile.cpu())
+            gathered.copy_(host)
+        else:
+            dist.all_gather_into_tensor(gathered, tile)
+
     def render_range(r):
         with torch.no_grad():
             rgb, depth = par(r[None])
@@ -231,7 +248,7 @@ def main():
         if exchange:
             tile[:n_rays, :3] = rgb[0]
             tile[:n_rays, 3] = depth[0]
-            dist.all_gather_into_tensor(gathered, tile)
+            all_gather_tiles()
         return rgb, depth
 
     def fence():
@@ -245,7 +262,7 @@ def main():
         par(rays[:, :256].contiguous())   # 8x32 and (fine pass) 8x64 shapes, projected variant when enabled
         par(rays[:, :4096].contiguous())
     if exchange:
-        dist.all_gather_into_tensor(gathered, tile)
+        all_gather_tiles()
     fence()
 
     def timed(steps):
@@ -268,7 +285,7 @@ def main():
         elapsed = time.perf_counter() - t0
         net.enable_kernel_timing(False)
         if world > 1:
-            tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            tmax = torch.tensor([elapsed], device="cpu" if args.rehearse_one_gpu else dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
         return elapsed, acc, rgb, depth
@@ -322,6 +339,8 @@ def main():
         "flop_per_ray": flop_per_ray(wl, projected), "flop_per_ray_reference_order": flop_per_ray(wl, False),
         "roofline": rl,
     }
+    if args.rehearse_one_gpu:
+        out["rehearsal"] = "ranks share ONE GPU, gloo transport: mechanics check, not a measurement"
 
     if world == 1 and args.projection != "off" and not args.no_reference_order:
         # the same frame in the reference's operation order (lin_z per sample): executed FLOPs = SURVEY.md 8d's count

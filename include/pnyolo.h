@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PNY_ABI_VERSION 4
+#define PNY_ABI_VERSION 5
 
 typedef enum pny_status {
     PNY_OK = 0,
@@ -230,6 +230,55 @@ int pny_scene_project(pny_scene* s, pny_stream stream);
 int pny_scene_last_mlp_stats(pny_scene* s, double* flops, double* flops_reference, double* kernel_ms, int* launches,
                              int* projected);
 int pny_scene_enable_timing(pny_scene* s, int enable);
+
+/* ---- Backward pass (callers: train/trainlib/PixelNerfTrainer.py:133-156 `loss.backward()`) ----
+ * What autograd computes in the reference for the parameters of mlp_coarse / mlp_fine through
+ * NeRFRenderer.composite (src/render/nerf.py:229-250), the output head (src/model/models.py:312-317), the cross-view
+ * mean (src/util/util.py:489-499) and ResnetFC.forward (src/model/resnetfc.py:134-186).  Exact-fp32 MFMA throughout.
+ * The forward call is the ordinary pny_render / pny_query (its optional z / per-sample outputs are what the backward
+ * needs); inside the backward call the MLP chain is evaluated once more in the reference's operation order with every
+ * GEMM operand stashed in HBM (bounded by PNYOLO_STASH_GB, default 16: larger batches are processed in chunks), then
+ * the dX chain and the weight-gradient GEMMs run over the stash.
+ * Not yet differentiated (documented gaps): the sample depths (the reference lets the fine pass's depth
+ * samples depend on the coarse depth, nerf.py:156-167), the latent / encoder, the rays. */
+
+/* Gradient target of the state_dict entry `name` ("mlp_coarse.blocks.2.fc_1.weight", ...): a device buffer of the
+ * parameter's shape (fp32, contiguous) that the backward calls write / add into.  NULL unbinds.  Borrowed until
+ * rebound; parameters without a bound target get no gradient. */
+int pny_model_bind_grad(pny_model* m, const char* name, float* grad_dev);
+
+/* Backward of pny_query: d_out_dev (n, d_out) = dL/d(out).  accumulate = 0 overwrites the bound gradients of the
+ * selected MLP, 1 adds to them. */
+int pny_query_backward(pny_scene* s, const float* xyz_dev, const float* viewdirs_dev, int64_t n, int coarse,
+                       const float* d_out_dev, int accumulate, pny_stream stream);
+
+/* Backward of pny_composite (src/render/nerf.py:229-250): g_* = dL/d(rgb (n,3)), dL/d(depth (n)), dL/d(weights (n,k)),
+ * any may be NULL.  d_sample_dev (n,k,4) = dL/d(per-sample [rgb, sigma]); d_z_dev (n,k), optional = dL/d(z) through
+ * the deltas and the depth sum. */
+int pny_composite_backward(const float* rays_dev, const float* z_dev, const float* sample_dev, int64_t n, int k,
+                           int white_bkgd, const float* g_rgb_dev, const float* g_depth_dev, const float* g_weights_dev,
+                           float* d_sample_dev, float* d_z_dev, pny_stream stream);
+
+/* What the forward pny_render call left in its optional outputs (pny_render_out z_* / sample_*). */
+typedef struct pny_render_saved {
+    const float* z_coarse;      /* (n, n_coarse) */
+    const float* sample_coarse; /* (n, n_coarse, 4) */
+    const float* z_fine;        /* (n, n_coarse+n_fine) */
+    const float* sample_fine;   /* (n, n_coarse+n_fine, 4) */
+} pny_render_saved;
+/* Upstream gradients w.r.t. the outputs of pny_render; any may be NULL (= zero). */
+typedef struct pny_render_grads {
+    const float* rgb_coarse;     /* (n,3) */
+    const float* depth_coarse;   /* (n) */
+    const float* weights_coarse; /* (n,n_coarse) */
+    const float* rgb_fine;
+    const float* depth_fine;
+    const float* weights_fine;
+} pny_render_grads;
+/* Backward of pny_render for one scene: composite backward + MLP backward of the fine pass (mlp_fine) and of the coarse
+ * pass (mlp_coarse), into the bound gradients (accumulate as above; with one shared MLP the two passes add up). */
+int pny_render_backward(pny_scene* s, const float* rays_dev, int64_t n, const pny_render_opts* opts,
+                        const pny_render_saved* saved, const pny_render_grads* grads, int accumulate, pny_stream stream);
 
 #ifdef __cplusplus
 }

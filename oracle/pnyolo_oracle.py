@@ -229,19 +229,34 @@ def _lin(sd, name, x):
     return torch.addmm(sd[name + ".bias"], x, sd[name + ".weight"].t())
 
 
+# Test aid for gradient comparisons: when set to a list, every relu input of resnetfc() appends its per-query-point
+# min |.| (B,) -- a point whose smallest |pre-activation| is below the fp32 agreement of two implementations has an
+# ambiguous relu mask, and its gradient is not comparable across implementations (the gradient is discontinuous there).
+RELU_TRACE = None
+
+
+def _relu(t, rows_per_point):
+    if RELU_TRACE is not None:
+        m = t.detach().abs().min(dim=-1)[0]
+        RELU_TRACE.append(m.reshape(rows_per_point, -1).min(dim=0)[0])
+    return torch.relu(t)
+
+
 def resnetfc(sd, z, x, ns, n_blocks=5, combine_layer=3):
     """src/model/resnetfc.py:134-186 (+ :53-62 block, util.py:489-499 combine):
     rows ordered view-major within a scene: row = v*B + b.  z (ns*B,L), x (ns*B,d_in)."""
     h = _lin(sd, "lin_in", x)
+    nv = ns
     for blk in range(n_blocks):
         if blk == combine_layer:
             h = h.reshape(ns, -1, h.shape[-1]).mean(dim=0)
+            nv = 1
         if blk < combine_layer:
             h = h + _lin(sd, "lin_z.%d" % blk, z)
-        net = _lin(sd, "blocks.%d.fc_0" % blk, torch.relu(h))
-        dx = _lin(sd, "blocks.%d.fc_1" % blk, torch.relu(net))
+        net = _lin(sd, "blocks.%d.fc_0" % blk, _relu(h, nv))
+        dx = _lin(sd, "blocks.%d.fc_1" % blk, _relu(net, nv))
         h = h + dx
-    return _lin(sd, "lin_out", torch.relu(h))
+    return _lin(sd, "lin_out", _relu(h, nv))
 
 
 class Scene:
@@ -299,9 +314,13 @@ def _query_rays(scene, rays, z, coarse, chunk):
 
 
 def render(scene, rays, n_coarse, n_fine, n_fine_depth, u_coarse, u_fine=None, u_fine2=None, g_depth=None,
-           depth_std=0.01, white_bkgd=True, lindisp=False, chunk=50000):
+           depth_std=0.01, white_bkgd=True, lindisp=False, chunk=50000, detach_fine_depth=False):
     """src/render/nerf.py:257-309 (forward) for SB=1: coarse pass, then fine pass on
-    sort(cat(z_coarse, z_fine, z_depth)) with the fine MLP.  The four random draws are inputs."""
+    sort(cat(z_coarse, z_fine, z_depth)) with the fine MLP.  The four random draws are inputs.
+    Under autograd the reference detaches the coarse weights for importance sampling (nerf.py:132) but NOT the coarse
+    depth the depth samples are centred on (nerf.py:296-298): the fine loss reaches the coarse MLP through the sample
+    positions.  detach_fine_depth=True cuts that path (a test aid for the stages of the backward pass; the default is
+    the reference's behaviour)."""
     rays = T(rays)
     res = {}
     zc = sample_coarse(rays, n_coarse, u_coarse, lindisp)
@@ -313,7 +332,7 @@ def render(scene, rays, n_coarse, n_fine, n_fine_depth, u_coarse, u_fine=None, u
         if n_fine - n_fine_depth > 0:
             samps.append(sample_fine(rays, wc, u_fine, u_fine2, n_coarse, lindisp))
         if n_fine_depth > 0:
-            samps.append(sample_fine_depth(rays, dc, g_depth, depth_std))
+            samps.append(sample_fine_depth(rays, dc.detach() if detach_fine_depth else dc, g_depth, depth_std))
         zf, _ = torch.sort(torch.cat(samps, dim=-1), dim=-1)
         of = _query_rays(scene, rays, zf, False, chunk)
         wf, rgbf, df = composite(rays, zf, of, white_bkgd)

@@ -9,8 +9,7 @@
 #include <string>
 #include <vector>
 
-#include "pny_common.h"
-#include "encoder.h"
+#include "api_internal.h"
 
 namespace pny {
 
@@ -20,89 +19,21 @@ int hip_fail(hipError_t e, const char* what) {
     g_err = std::string("HIP error: ") + hipGetErrorString(e) + " in " + what;
     return PNY_ERR_HIP;
 }
-static int fail(int code, const std::string& msg) {
+int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
 }
-
-struct HostTensor {
-    std::vector<int64_t> shape;
-    std::vector<float> data;
-};
-
-struct DevBuf {
-    void* p = nullptr;
-    size_t bytes = 0;
-    int reserve(size_t need) {
-        if (need <= bytes) return 0;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        bytes = 0;
-        hipError_t e = hipMalloc(&p, need);
-        if (e != hipSuccess) return hip_fail(e, "hipMalloc(workspace)");
-        bytes = need;
-        return 0;
-    }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        bytes = 0;
-    }
-    float* f() const { return reinterpret_cast<float*>(p); }
-};
 
 }  // namespace pny
 
 using namespace pny;
 
-struct pny_model {
-    pny_model_desc desc;
-    std::map<std::string, HostTensor> host;  // state_dict tensors as loaded
-    bool finalized = false;
-    bool use_fine = true;
-    DevBuf packed;                            // all MLP weights, one allocation
-    MlpWeights coarse{}, fine{};
-    EncoderWeights enc;                       // folded conv+bn (encoder.h)
-    bool has_encoder = false;
-    // lin_z[0..nvb) of the coarse / fine MLP stacked into one (nvb*512 x d_latent) pixel-wise map
-    ConvLayer zproj[2];
-    std::vector<float*> zproj_allocs;
-    bool has_zproj = false;
-    uint64_t generation = 0;                  // bumped by every finalize (scenes re-project)
-};
-
-struct pny_scene {
-    pny_model* m = nullptr;
-    int ns = 0, L = 0, hl = 0, wl = 0;  // latent
-    int width = 0, height = 0;
-    bool have_cams = false, have_latent = false;
-    int cam_ns = 0;
-    Cam cams[MAX_VIEWS];  // host copy; handed to every MLP launch as kernel arguments
-    DevBuf latent, work, scratch, enc_work;
-    // projected latent of the coarse [0] / fine [1] MLP (see ensure_projection)
-    DevBuf zp[2];
-    bool zp_valid[2] = {false, false};
-    uint64_t zp_generation = 0;
-    int zp_mode = PNY_PROJECTION_AUTO;
-    bool last_projected = false;
-    double last_flops_ref = 0.0;
-    // timing of the MLP launches of the last call
-    bool timing = false;
-    std::vector<hipEvent_t> ev;
-    int ev_used = 0;
-    double last_flops = 0.0;
-    int last_launches = 0;
-    // stream the last call on this scene was enqueued on (see enter_stream)
-    hipStream_t last_stream = nullptr;
-    bool has_last_stream = false;
-    hipEvent_t order_ev = nullptr;
-};
-
 // A scene's state (latent, projected maps, workspace, cross-view slab) is written and read by the kernels of
 // successive calls without any host synchronisation, which is only ordered if those calls share a stream.  When a
 // call arrives on a DIFFERENT stream than the previous call on the same scene, the new stream is made to wait for
 // everything the previous call enqueued (one event record + one stream wait, paid only on a stream switch).
-static int enter_stream(pny_scene* s, hipStream_t st) {
+namespace pny {
+int enter_stream(pny_scene* s, hipStream_t st) {
     if (s->has_last_stream && s->last_stream != st) {
         if (!s->order_ev && hipEventCreateWithFlags(&s->order_ev, hipEventDisableTiming) != hipSuccess) {
             s->order_ev = nullptr;
@@ -118,6 +49,7 @@ static int enter_stream(pny_scene* s, hipStream_t st) {
     s->has_last_stream = true;
     return 0;
 }
+}  // namespace pny
 
 // ---------------------------------------------------------------------------------- packing
 // A-operand order of v_mfma_f32_32x32x2_f32 for H^T = W X^T (see mlp.hip): for k-iteration j (8
@@ -165,7 +97,7 @@ struct PackPlan {
     }
 };
 
-static int pack_mlp(pny_model* m, const std::string& pre, MlpWeights& w, PackPlan& plan) {
+static int pack_mlp(pny_model* m, const std::string& pre, MlpWeights& w, MlpWeightsT& wt, PackPlan& plan) {
     const pny_model_desc& d = m->desc;
     const int d_in = 3 + 6 * d.num_freqs + 3;
     const int nvb = d.combine_layer < d.n_blocks ? d.combine_layer : d.n_blocks;
@@ -215,6 +147,26 @@ static int pack_mlp(pny_model* m, const std::string& pre, MlpWeights& w, PackPla
     }
     if ((rc = plain(pre + "lin_out.weight", {d.d_out, HID}, &w.w_out))) return rc;
     if ((rc = plain(pre + "lin_out.bias", {d.d_out}, &w.b_out))) return rc;
+    // transposed copies for the backward chain (dX^T = W^T dY^T, mlp_bwd.hip): same operand order, W^T as the matrix
+    auto packedT = [&](const std::string& name, int n_out, int k_in, const float** slot) -> int {
+        if ((rc = need(m, name, {n_out, k_in}, &t))) return rc;
+        std::vector<float> wtr((size_t)n_out * k_in);
+        for (int n = 0; n < n_out; ++n)
+            for (int k = 0; k < k_in; ++k) wtr[(size_t)k * n_out + n] = t->data[(size_t)n * k_in + k];
+        while (plan.blob.size() % 16) plan.blob.push_back(0.f);
+        const size_t off = plan.blob.size();
+        // W^T is (k_in x n_out): its rows (the GEMM's outputs) must be 512; its K (= n_out) is padded to a ring multiple
+        pack_layer(wtr.data(), k_in, n_out, n_out == HID ? HID : D_IN_PAD, plan.blob);
+        plan.fix.push_back({slot, off});
+        return 0;
+    };
+    if (d.d_out > D_IN_PAD) return fail(PNY_ERR_ARG, "d_out > 64");
+    if ((rc = packedT(pre + "lin_out.weight", d.d_out, HID, &wt.wT_out))) return rc;
+    for (int b = 0; b < d.n_blocks; ++b) {
+        const std::string p = pre + "blocks." + std::to_string(b);
+        if ((rc = packedT(p + ".fc_0.weight", HID, HID, &wt.wT_fc0[b]))) return rc;
+        if ((rc = packedT(p + ".fc_1.weight", HID, HID, &wt.wT_fc1[b]))) return rc;
+    }
     return 0;
 }
 
@@ -272,13 +224,16 @@ int pny_model_finalize(pny_model* m) {
     PackPlan plan;
     int rc;
     PNY_HIP(hipDeviceSynchronize());  // a re-finalize must not overwrite weights a running kernel reads
-    if ((rc = pack_mlp(m, "mlp_coarse.", m->coarse, plan))) return rc;
-    if (m->desc.has_fine && (rc = pack_mlp(m, "mlp_fine.", m->fine, plan))) return rc;
+    if ((rc = pack_mlp(m, "mlp_coarse.", m->coarse, m->coarse_t, plan))) return rc;
+    if (m->desc.has_fine && (rc = pack_mlp(m, "mlp_fine.", m->fine, m->fine_t, plan))) return rc;
     if (plan.blob.size() * sizeof(float) >= (1ull << 31)) return fail(PNY_ERR_ARG, "packed weights exceed the 2 GiB raw-buffer range");
     if ((rc = m->packed.reserve(plan.blob.size() * sizeof(float)))) return rc;
     PNY_HIP(hipMemcpy(m->packed.p, plan.blob.data(), plan.blob.size() * sizeof(float), hipMemcpyHostToDevice));
     for (auto& f : plan.fix) *f.first = m->packed.f() + f.second;
-    if (!m->desc.has_fine) m->fine = m->coarse;
+    if (!m->desc.has_fine) {
+        m->fine = m->coarse;
+        m->fine_t = m->coarse_t;
+    }
     // encoder weights are optional (a scene may be fed through pny_scene_set_latent instead)
     // stacked lin_z maps for the projected-latent variant
     for (float* p : m->zproj_allocs) (void)hipFree(p);
@@ -343,6 +298,8 @@ void pny_scene_destroy(pny_scene* s) {
     s->enc_work.release();
     s->zp[0].release();
     s->zp[1].release();
+    for (DevBuf* b : {&s->x_stash, &s->dy_stash, &s->dw_partial, &s->dw_bias, &s->dw_tables, &s->d_samp, &s->out_tmp, &s->dz_tmp})
+        b->release();
     for (auto e : s->ev) (void)hipEventDestroy(e);
     if (s->order_ev) (void)hipEventDestroy(s->order_ev);
     delete s;
@@ -529,7 +486,8 @@ int pny_gen_rays(const float* poses_host, int b, int width, int height, const fl
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------- MLP launch
-static int check_ready(pny_scene* s, const char* who) {
+namespace pny {
+int check_ready(pny_scene* s, const char* who) {
     if (!s) return fail(PNY_ERR_ARG, std::string(who) + ": null scene");
     if (!s->m->finalized) return fail(PNY_ERR_STATE, std::string(who) + ": weights not finalized (pny_model_finalize)");
     if (!s->have_latent) return fail(PNY_ERR_STATE, std::string(who) + ": scene has no latent (pny_scene_encode / pny_scene_set_latent)");
@@ -540,7 +498,8 @@ static int check_ready(pny_scene* s, const char* who) {
     return 0;
 }
 
-static int view_blocks(const pny_model_desc& d) { return d.combine_layer < d.n_blocks ? d.combine_layer : d.n_blocks; }
+int view_blocks(const pny_model_desc& d) { return d.combine_layer < d.n_blocks ? d.combine_layer : d.n_blocks; }
+}  // namespace pny
 
 // GEMM FLOPs (2 per MAC, unpadded) per query point: as the reference computes it (with_lin_z) or as the
 // projected-latent variant executes it (lin_z moved to the per-scene projection).
@@ -580,21 +539,20 @@ static int ensure_projection(pny_scene* s, int which, long long n_points, hipStr
     return 0;
 }
 
-static int run_mlp(pny_scene* s, int mode, const float* xyz, const float* dirs, const float* rays, const float* z,
-                   int K, long long n_points, int coarse, float* out, hipStream_t st) {
-    if (n_points == 0) return 0;
+namespace pny {
+int fill_mlp_args(pny_scene* s, int mode, const float* xyz, const float* dirs, const float* rays, const float* z, int K,
+                  long long n_points, int coarse, float* out, MlpArgs* pa) {
     const pny_model_desc& d = s->m->desc;
-    MlpArgs a;
+    MlpArgs& a = *pa;
     memset(&a, 0, sizeof(a));
     const bool fine_w = !(coarse || !d.has_fine || !s->m->use_fine);
     a.w = fine_w ? s->m->fine : s->m->coarse;
     a.w_base = s->m->packed.f();
     a.w_bytes = (unsigned)s->m->packed.bytes;
     a.latent = s->latent.f();
-    int rc;
-    if ((rc = ensure_projection(s, fine_w ? 1 : 0, n_points, st, &a.zp))) return rc;
+    a.zp = nullptr;
     a.zp_stride = view_blocks(d) * HID;
-    a.tap_stride = a.zp ? a.zp_stride : s->L;
+    a.tap_stride = s->L;
     memcpy(a.cams, s->cams, sizeof(Cam) * (size_t)s->ns);
     a.xyz = xyz;
     a.dirs = dirs;
@@ -619,21 +577,40 @@ static int run_mlp(pny_scene* s, int mode, const float* xyz, const float* dirs, 
     const float lsy = (float)s->hl / ((float)s->hl - 1.0f) * 2.0f;
     a.sx = lsx / (float)s->width;
     a.sy = lsy / (float)s->height;
+    const long long tiles = (n_points + 63) / 64;
+    if (tiles > 0x7fffffffll) return fail(PNY_ERR_ARG, "too many points for one launch");
+    a.n_tiles = (int)tiles;
+    a.idx32 = (tiles * 64) < 0xffffffffll;
+    if (mode == 1 && (reinterpret_cast<uintptr_t>(rays) & 15)) return fail(PNY_ERR_ARG, "rays must be 16-byte aligned");
+    int rc;
+    if ((rc = s->scratch.reserve(mlp_scratch_floats() * sizeof(float)))) return rc;
+    a.scratch = s->scratch.f();
+    return 0;
+}
+}  // namespace pny
+
+static int run_mlp(pny_scene* s, int mode, const float* xyz, const float* dirs, const float* rays, const float* z,
+                   int K, long long n_points, int coarse, float* out, hipStream_t st) {
+    if (n_points == 0) return 0;
+    const pny_model_desc& d = s->m->desc;
+    MlpArgs a;
+    int rc;
+    if ((rc = fill_mlp_args(s, mode, xyz, dirs, rays, z, K, n_points, coarse, out, &a))) return rc;
+    const bool fine_w = !(coarse || !d.has_fine || !s->m->use_fine);
+    if ((rc = ensure_projection(s, fine_w ? 1 : 0, n_points, st, &a.zp))) return rc;
+    a.tap_stride = a.zp ? a.zp_stride : s->L;
     const int variant = mlp_pick_variant(n_points);
     const int tm = mlp_tile_samples(variant);
     const long long tiles = (n_points + tm - 1) / tm;
     if (tiles > 0x7fffffffll) return fail(PNY_ERR_ARG, "too many points for one launch");
     a.n_tiles = (int)tiles;
     a.idx32 = (tiles * tm) < 0xffffffffll;
-    if (mode == 1 && (reinterpret_cast<uintptr_t>(rays) & 15)) return fail(PNY_ERR_ARG, "rays must be 16-byte aligned");
     int grid = mlp_max_grid(variant);
     if (const char* e = getenv("PNYOLO_GRID")) {  // diagnostic: fewer resident workgroups
         const int g = atoi(e);
         if (g > 0 && g < grid) grid = g;
     }
     if (tiles < grid) grid = (int)tiles;
-    if ((rc = s->scratch.reserve(mlp_scratch_floats() * sizeof(float)))) return rc;
-    a.scratch = s->scratch.f();
     if (s->timing) {
         while ((int)s->ev.size() < s->ev_used + 2) {
             hipEvent_t e;

@@ -1,0 +1,108 @@
+// Private declarations shared by the host-side translation units of libpnyolo (api.hip, train_api.hip).
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "pny_common.h"
+#include "encoder.h"
+
+namespace pny {
+
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int reserve(size_t need) {
+        if (need <= bytes) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        hipError_t e = hipMalloc(&p, need);
+        if (e != hipSuccess) return hip_fail(e, "hipMalloc(workspace)");
+        bytes = need;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    float* f() const { return reinterpret_cast<float*>(p); }
+};
+
+
+int fail(int code, const std::string& msg);
+
+// transposed packed weights of one MLP (A operands of the backward chain, mlp_bwd.hip)
+struct MlpWeightsT {
+    const float* wT_out;
+    const float* wT_fc0[MAX_BLOCKS];
+    const float* wT_fc1[MAX_BLOCKS];
+};
+
+}  // namespace pny
+
+using namespace pny;  // private header of host-side translation units only
+
+struct pny_model {
+    pny_model_desc desc;
+    std::map<std::string, HostTensor> host;  // state_dict tensors as loaded
+    bool finalized = false;
+    bool use_fine = true;
+    DevBuf packed;                            // all MLP weights, one allocation
+    MlpWeights coarse{}, fine{};
+    MlpWeightsT coarse_t{}, fine_t{};        // transposed packs for the backward chain
+    std::map<std::string, float*> grads;     // gradient targets by state_dict name (pny_model_bind_grad)
+    EncoderWeights enc;                       // folded conv+bn (encoder.h)
+    bool has_encoder = false;
+    // lin_z[0..nvb) of the coarse / fine MLP stacked into one (nvb*512 x d_latent) pixel-wise map
+    ConvLayer zproj[2];
+    std::vector<float*> zproj_allocs;
+    bool has_zproj = false;
+    uint64_t generation = 0;                  // bumped by every finalize (scenes re-project)
+};
+
+struct pny_scene {
+    pny_model* m = nullptr;
+    int ns = 0, L = 0, hl = 0, wl = 0;  // latent
+    int width = 0, height = 0;
+    bool have_cams = false, have_latent = false;
+    int cam_ns = 0;
+    Cam cams[MAX_VIEWS];  // host copy; handed to every MLP launch as kernel arguments
+    DevBuf latent, work, scratch, enc_work;
+    // projected latent of the coarse [0] / fine [1] MLP (see ensure_projection)
+    DevBuf zp[2];
+    bool zp_valid[2] = {false, false};
+    uint64_t zp_generation = 0;
+    int zp_mode = PNY_PROJECTION_AUTO;
+    bool last_projected = false;
+    double last_flops_ref = 0.0;
+    // timing of the MLP launches of the last call
+    bool timing = false;
+    std::vector<hipEvent_t> ev;
+    int ev_used = 0;
+    double last_flops = 0.0;
+    int last_launches = 0;
+    // stream the last call on this scene was enqueued on (see enter_stream)
+    // training workspace (train_api.hip)
+    DevBuf x_stash, dy_stash, dw_partial, dw_bias, dw_tables, d_samp, out_tmp, dz_tmp;
+    std::vector<char> table_host;
+    hipStream_t last_stream = nullptr;
+    bool has_last_stream = false;
+    hipEvent_t order_ev = nullptr;
+};
+
+
+namespace pny {
+int enter_stream(pny_scene* s, hipStream_t st);
+int check_ready(pny_scene* s, const char* who);
+int view_blocks(const pny_model_desc& d);
+// MlpArgs of a launch on this scene in the reference's operation order (no projected latent); tiles of 64 samples
+int fill_mlp_args(pny_scene* s, int mode, const float* xyz, const float* dirs, const float* rays, const float* z, int K,
+                  long long n_points, int coarse, float* out, MlpArgs* a);
+}  // namespace pny

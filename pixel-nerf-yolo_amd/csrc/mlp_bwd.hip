@@ -1,0 +1,501 @@
+// Backward pass of the conditioned ResNet MLP for gfx950 (MI355X) -- SURVEY.md 8f-1: the gradient the reference gets from
+// loss.backward() through PixelNeRFNet.forward / ResnetFC.forward (reference src/model/resnetfc.py:134-186,
+// src/model/models.py:153-318) w.r.t. every MLP parameter.
+//
+// Three kernels, all exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), all on 64-sample tiles:
+//   1. pny_mlp_kernel<.., STASH> (mlp.hip): the forward chain once more in the reference's operation order, writing
+//      every GEMM's B operand X_l (relu'd activations, gathered latent, positional code) to an HBM stash in the LDS
+//      operand layout [feature/4][sample] float4 (pny_common.h StashLayout).
+//   2. pny_mlp_bwd_kernel (here): the dX chain.  Same transposed formulation and weight-stream ring as the forward:
+//      dX^T[k][m] = W^T[k][n] dY^T[n][m] with the TRANSPOSED packed weights as the A operand and dY^T in the LDS
+//      activation buffer as the B operand; the gradient of the residual stream stays in the accumulators (dh), a second
+//      accumulator set carries the block-internal gradient.  relu masks come from the stash (x > 0); every dY_l a
+//      weight gradient needs is written to a second stash in the same layout.
+//   3. pny_dw_gemm_kernel (here): dW_l[n][k] = sum_samples dY_l[s][n] X_l[s][k] as an LDS-staged split-K GEMM over the
+//      two stashes (256x256 output tile per workgroup, K = samples x views), bias gradients as column sums of dY_l in
+//      the same pass; a deterministic reduction over the K splits writes the gradients in the state_dict's layout.
+// Per-tile atomics into dW were rejected (1 MB of read-modify-write per layer per 64 samples).
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "mlp_core.h"
+
+namespace pny {
+
+// ---------------------------------------------------------------------------------------------- chain kernel
+__device__ __forceinline__ WStream wstream_raw(const float* base, unsigned bytes, int lane) {
+    WStream w;
+    w.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
+    w.base = reinterpret_cast<const char*>(base);
+    w.lane_off = 16u * (unsigned)lane;
+    return w;
+}
+
+template <int NT, int MT>
+__device__ __forceinline__ void acc_zero(f32x16 (&t)[NT][MT]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[nt][mt][r] = 0.f;
+}
+
+// act[feature/4][m] = acc (no activation): the B operand of the next transposed GEMM; optionally also to the dY stash.
+template <int NT, int MT, bool TO_LDS, bool TO_GLOBAL>
+__device__ __forceinline__ void store_plain(const f32x16 (&acc)[NT][MT], float4* __restrict__ act, float4* __restrict__ g,
+                                            int wave, int lane) {
+    constexpr int TMc = 32 * MT;
+    const int m0 = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = make_float4(acc[nt][mt][4 * q + 0], acc[nt][mt][4 * q + 1], acc[nt][mt][4 * q + 2],
+                                             acc[nt][mt][4 * q + 3]);
+                const int idx = (8 * NT * wave + 8 * nt + 2 * q + hh) * TMc + 32 * mt + m0;
+                if (TO_LDS) act[idx] = v;
+                if (TO_GLOBAL) g[idx] = v;
+            }
+}
+
+// acc = (x > 0) ? acc : 0 with x = the stashed relu'd activation of the same element (accumulator layout).
+template <int NT, int MT>
+__device__ __forceinline__ void mask_by(f32x16 (&acc)[NT][MT], const float4* __restrict__ x, int wave, int lane) {
+    constexpr int TMc = 32 * MT;
+    const int m0 = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            float4 xv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xv[q] = x[(8 * NT * wave + 8 * nt + 2 * q + hh) * TMc + 32 * mt + m0];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc[nt][mt][4 * q + 0] = xv[q].x > 0.f ? acc[nt][mt][4 * q + 0] : 0.f;
+                acc[nt][mt][4 * q + 1] = xv[q].y > 0.f ? acc[nt][mt][4 * q + 1] : 0.f;
+                acc[nt][mt][4 * q + 2] = xv[q].z > 0.f ? acc[nt][mt][4 * q + 2] : 0.f;
+                acc[nt][mt][4 * q + 3] = xv[q].w > 0.f ? acc[nt][mt][4 * q + 3] : 0.f;
+            }
+        }
+}
+
+template <int NT, int MT>
+__device__ __forceinline__ void acc_load(f32x16 (&acc)[NT][MT], const float4* __restrict__ g, int wave, int lane) {
+    constexpr int TMc = 32 * MT;
+    const int m0 = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = g[(8 * NT * wave + 8 * nt + 2 * q + hh) * TMc + 32 * mt + m0];
+                acc[nt][mt][4 * q + 0] = v.x;
+                acc[nt][mt][4 * q + 1] = v.y;
+                acc[nt][mt][4 * q + 2] = v.z;
+                acc[nt][mt][4 * q + 3] = v.w;
+            }
+}
+
+// Reverse of one pre-activation residual block (reference resnetfc.py:53-62: net = fc_0(relu(h)); h' = h + fc_1(relu(net))):
+//   dnet = (fc_1^T dh') * [net > 0];   dh = dh' + (fc_0^T dnet) * [h > 0]   (times `scale` = 1/NS below the cross-view mean)
+// dh' arrives in the accumulators `dh` and leaves as dh.  Written to the dY stash: dnet (dY of fc_0) and dh (dY of
+// lin_z of this block / fc_1 of the previous one / lin_in).
+template <class C>
+__device__ __forceinline__ void block_bwd(f32x16 (&dh)[C::NT][C::MT], WRing<C::WDEPTH, C::NT>& ring, const WStream& ws,
+                                          const WSeg& s_fc1t, const WSeg& s_fc0t, const WSeg& after, float4* act,
+                                          const float4* x_h, const float4* x_net, float4* dy_dnet, float4* dy_dh,
+                                          float scale, int wave, int lane) {
+    constexpr int NT = C::NT, MT = C::MT;
+    f32x16 t[NT][MT];
+    __syncthreads();  // every wave is done reading the buffer (previous GEMM)
+    store_plain<NT, MT, true, false>(dh, act, nullptr, wave, lane);
+    __syncthreads();
+    acc_zero<NT, MT>(t);
+    gemm_run<C>(t, ring, ws, s_fc1t, s_fc0t, act, lane);
+    mask_by<NT, MT>(t, x_net, wave, lane);
+    __syncthreads();
+    store_plain<NT, MT, true, true>(t, act, dy_dnet, wave, lane);
+    __syncthreads();
+    acc_zero<NT, MT>(t);
+    gemm_run<C>(t, ring, ws, s_fc0t, after, act, lane);
+    mask_by<NT, MT>(t, x_h, wave, lane);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dh[nt][mt][r] = (dh[nt][mt][r] + t[nt][mt][r]) * scale;
+    store_plain<NT, MT, false, true>(dh, nullptr, dy_dh, wave, lane);
+}
+
+template <class C>
+__global__ __launch_bounds__(C::THREADS, C::WPS) void pny_mlp_bwd_kernel(const BwdArgs a) {
+    constexpr int NT = C::NT, MT = C::MT, TMc = C::TM;
+    static_assert(TMc == 64, "the stash layout is defined on 64-sample tiles");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float4* act = reinterpret_cast<float4*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nb = a.n_blocks;
+    const int nvb = a.combine_layer < nb ? a.combine_layer : nb;
+    const int npost = nb - nvb;
+    const WStream ws = wstream_raw(a.w_base, a.w_bytes, lane);
+    const WSeg s_out = wseg<NT>(ws, a.wT_out, D_IN_PAD / 8, 0, D_IN_PAD / 8, wave);
+    auto fc1t = [&](int b) { return wseg<NT>(ws, a.wT_fc1[b], 64, 0, 64, wave); };
+    auto fc0t = [&](int b) { return wseg<NT>(ws, a.wT_fc0[b], 64, 0, 64, wave); };
+    WRing<C::WDEPTH, NT> ring;
+    ring_fill(ring, ws, s_out);
+    const float inv_ns = 1.0f / (float)a.NS;
+
+    for (long long tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const float* x_rec = a.x_stash + tile * a.lay.x_tile;
+        float* dy_rec = a.dy_stash + tile * a.lay.dy_tile;
+        auto x_post = [&](int i) { return reinterpret_cast<const float4*>(x_rec + a.lay.x_post + (size_t)i * STASH_SLOT); };
+        auto x_act = [&](int v, int i) {
+            return reinterpret_cast<const float4*>(x_rec + (size_t)v * a.lay.x_view + a.lay.x_act + (size_t)i * STASH_SLOT);
+        };
+        float4* dy_draw = reinterpret_cast<float4*>(dy_rec + a.lay.dy_post);
+        auto dy_post = [&](int i) { return reinterpret_cast<float4*>(dy_rec + a.lay.dy_post + STASH_SMALL + (size_t)i * STASH_SLOT); };
+        auto dy_view = [&](int v, int i) { return reinterpret_cast<float4*>(dy_rec + (size_t)v * a.lay.dy_view + (size_t)i * STASH_SLOT); };
+
+        // ---- head: gradient w.r.t. lin_out's output through sigmoid / relu (reference models.py:312-317), as the B
+        // operand of lin_out^T (d_out rows padded to 64) and as the dY of lin_out for the weight-gradient GEMM
+        __syncthreads();
+        for (int idx = tid; idx < (D_IN_PAD / 4) * TMc; idx += C::THREADS) {
+            const int kg = idx / TMc, m = idx % TMc;
+            const long long s = tile * TMc + m;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (s < a.n_points) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int o = 4 * kg + c;
+                    if (o < a.d_out) {
+                        const float g = a.d_out_grad[s * a.d_out + o];
+                        if (a.yolo) {
+                            v[c] = g;
+                        } else {
+                            const float y = a.out[s * a.d_out + o];
+                            v[c] = o < 3 ? g * (y * (1.0f - y)) : (o == 3 ? (y > 0.f ? g : 0.f) : g);
+                        }
+                    }
+                }
+            }
+            const float4 v4 = make_float4(v[0], v[1], v[2], v[3]);
+            act[idx] = v4;
+            dy_draw[idx] = v4;
+        }
+        __syncthreads();
+        f32x16 dh[NT][MT];
+        acc_zero<NT, MT>(dh);
+        gemm_run<C>(dh, ring, ws, s_out, fc1t(nb - 1), act, lane);
+        mask_by<NT, MT>(dh, x_post(2 * npost), wave, lane);                 // relu(h_top) > 0
+        store_plain<NT, MT, false, true>(dh, nullptr, dy_post(0), wave, lane);  // dh_top: dY of the last block's fc_1
+
+        // ---- post-combine blocks, last to first; the first of them also applies the 1/NS of the cross-view mean
+        for (int b = nb - 1; b >= nvb; --b) {
+            const int i = b - nvb;
+            const WSeg after = b > nvb ? fc1t(b - 1) : (nvb > 0 ? fc1t(nvb - 1) : s_out);
+            block_bwd<C>(dh, ring, ws, fc1t(b), fc0t(b), after, act, x_post(2 * i), x_post(2 * i + 1), dy_post(1 + 2 * i),
+                         dy_post(2 + 2 * i), b == nvb ? inv_ns : 1.0f, wave, lane);
+        }
+        // dhm: what every view's last per-view block receives (dh_top itself when there is no post-combine block)
+        const float4* dhm = npost > 0 ? dy_post(2) : dy_post(0);
+        for (int v = 0; v < a.NS && nvb > 0; ++v) {
+            if (v > 0) acc_load<NT, MT>(dh, dhm, wave, lane);
+            for (int b = nvb - 1; b >= 0; --b) {
+                const WSeg after = b > 0 ? fc1t(b - 1) : (v + 1 < a.NS ? fc1t(nvb - 1) : s_out);
+                block_bwd<C>(dh, ring, ws, fc1t(b), fc0t(b), after, act, x_act(v, 2 * b), x_act(v, 2 * b + 1),
+                             dy_view(v, 2 * b), dy_view(v, 2 * b + 1), 1.0f, wave, lane);
+            }
+        }
+    }
+}
+
+void launch_mlp_bwd(const BwdArgs& a, int grid, hipStream_t st) {
+    using C = Cfg<2, 2>;
+    static bool attr_set[64] = {};
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    dev_ &= 63;
+    if (!attr_set[dev_]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pny_mlp_bwd_kernel<C>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+        attr_set[dev_] = true;
+    }
+    hipLaunchKernelGGL((pny_mlp_bwd_kernel<C>), dim3(grid), dim3(C::THREADS), C::LDS, st, a);
+}
+
+// ---------------------------------------------------------------------------------------------- weight-gradient GEMM
+// C[n][k] = sum over (tile, view) of sum_m dY[kgA][m] X[kgX][m]: both operands arrive in the stash layout (sample
+// index fastest within a feature quad), are loaded as whole 1-KB rows and TRANSPOSED on their way into LDS to
+// [sample][feature] images with a row stride of 260 floats: the staging ds_write_b128 (8 lanes x 4 banks) and the
+// fragment ds_read_b32 (32 consecutive features of one sample) are both conflict-free.  8 waves = 2 (rows) x 4 (cols),
+// 128 x 64 per wave = 4 x 2 MFMA tiles.  The next tile's rows are fetched into registers underneath the MFMAs.
+constexpr int DW_LD = 260;
+constexpr int DW_TILE = 256;
+constexpr size_t DW_LDS_BYTES = (size_t)2 * 64 * DW_LD * sizeof(float);
+
+__global__ __launch_bounds__(512, 2) void pny_dw_gemm_kernel(const DwJob* __restrict__ jobs, const DwItem* __restrict__ items,
+                                                             const float* __restrict__ x_stash,
+                                                             const float* __restrict__ dy_stash, long long x_tile,
+                                                             long long dy_tile, float* __restrict__ partial,
+                                                             float* __restrict__ bias_partial) {
+    extern __shared__ __attribute__((aligned(16))) float dw_lds[];
+    float* la = dw_lds;
+    float* lx = dw_lds + 64 * DW_LD;
+    const DwItem it = items[blockIdx.x];
+    const DwJob jb = jobs[it.job];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3, hh = lane >> 5, l31 = lane & 31;
+    const int row0 = it.mt * DW_TILE, col0 = it.nt * DW_TILE;
+    const int m = tid & 63, kg_t = tid >> 6;  // staging: this thread's sample and first feature quad of the slab
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    bool live_a[4], live_x[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) live_a[i] = row0 + wr * 128 + 32 * i < jb.a_rows;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) live_x[j] = col0 + wc * 64 + 32 * j < jb.x_cols;
+
+    float4 ra[8], rx[8];
+    auto fetch = [&](int tv) {
+        const int tile = tv / jb.n_views, v = tv - tile * jb.n_views;
+        const float4* ga = reinterpret_cast<const float4*>(dy_stash + (long long)tile * dy_tile + jb.a_off + (long long)v * jb.a_view) + (row0 / 4) * 64;
+        const float4* gx = reinterpret_cast<const float4*>(x_stash + (long long)tile * x_tile + jb.x_off + (long long)v * jb.x_view) + (col0 / 4) * 64;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int kg = kg_t + 8 * i;
+            ra[i] = (row0 + 4 * kg < jb.a_rows) ? ga[kg * 64 + m] : make_float4(0.f, 0.f, 0.f, 0.f);
+            rx[i] = (col0 + 4 * kg < jb.x_cols) ? gx[kg * 64 + m] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    if (it.tv_lo < it.tv_hi) fetch(it.tv_lo);
+    for (int tv = it.tv_lo; tv < it.tv_hi; ++tv) {
+        __syncthreads();  // the previous tile's fragments have been read
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int kg = kg_t + 8 * i;
+            *reinterpret_cast<float4*>(la + m * DW_LD + 4 * kg) = ra[i];
+            *reinterpret_cast<float4*>(lx + m * DW_LD + 4 * kg) = rx[i];
+        }
+        __syncthreads();
+        if (tv + 1 < it.tv_hi) fetch(tv + 1);
+        const float* pa = la + hh * DW_LD + wr * 128 + l31;
+        const float* px = lx + hh * DW_LD + wc * 64 + l31;
+#pragma unroll 4
+        for (int ks = 0; ks < 32; ++ks) {
+            float av[4], xv[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) av[i] = pa[2 * ks * DW_LD + 32 * i];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) xv[j] = px[2 * ks * DW_LD + 32 * j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (live_a[i]) {
+                    bsum[i] += av[i];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        if (live_x[j]) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], xv[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // partial tile: P[split][row][col], row stride = the job's padded column count
+    float* P = partial + it.part_off;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (!live_a[i] || !live_x[j]) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + wr * 128 + 32 * i + 8 * (r >> 2) + 4 * hh + (r & 3);
+                const int col = col0 + wc * 64 + 32 * j + l31;
+                if (row < jb.a_rows && col < jb.x_cols) P[(long long)row * jb.x_cols + col] = acc[i][j][r];
+            }
+        }
+    if (it.nt == 0 && wc == 0) {  // column sums of dY (bias gradients): the two lane halves hold alternate samples
+        float* B = bias_partial + it.bias_off;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float s = bsum[i] + __shfl_xor(bsum[i], 32, 64);
+            const int row = row0 + wr * 128 + 32 * i + l31;
+            if (hh == 0 && live_a[i] && row < jb.a_rows) B[row] = s;
+        }
+    }
+}
+
+// grad (+)= sum over splits of the job's partial tiles, in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void pny_dw_reduce_kernel(const DwTarget* __restrict__ targets, const float* __restrict__ partial,
+                                                            const float* __restrict__ bias_partial, int accumulate) {
+    const DwTarget t = targets[blockIdx.y];
+    const long long n_w = (long long)t.rows * t.cols;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n_w) {
+        if (!t.w) return;
+        const int row = (int)(idx / t.cols), col = (int)(idx - (long long)row * t.cols);
+        const float* p = partial + t.part_off + (long long)row * t.pcols + col;
+        float s = 0.f;
+        for (int k = 0; k < t.splits; ++k) s += p[(long long)k * t.prows * t.pcols];
+        t.w[idx] = accumulate ? t.w[idx] + s : s;
+    } else if (idx < n_w + t.rows) {
+        const int row = (int)(idx - n_w);
+        const float* p = bias_partial + t.bias_off + row;
+        float s = 0.f;
+        for (int k = 0; k < t.splits; ++k) s += p[(long long)k * t.prows];
+        if (t.b0) t.b0[row] = accumulate ? t.b0[row] + s : s;
+        if (t.b1) t.b1[row] = accumulate ? t.b1[row] + s : s;
+    }
+}
+
+void launch_dw_gemm(const DwJob* jobs_dev, const DwItem* items_dev, int n_items, const float* x_stash, const float* dy_stash,
+                    long long x_tile, long long dy_tile, float* partial, float* bias_partial, hipStream_t st) {
+    static bool attr_set[64] = {};
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    dev_ &= 63;
+    if (!attr_set[dev_]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pny_dw_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)DW_LDS_BYTES);
+        attr_set[dev_] = true;
+    }
+    if (n_items <= 0) return;
+    hipLaunchKernelGGL(pny_dw_gemm_kernel, dim3(n_items), dim3(512), DW_LDS_BYTES, st, jobs_dev, items_dev, x_stash, dy_stash,
+                       x_tile, dy_tile, partial, bias_partial);
+}
+
+void launch_dw_reduce(const DwTarget* targets_dev, int n_targets, long long max_elems, const float* partial,
+                      const float* bias_partial, int accumulate, hipStream_t st) {
+    if (n_targets <= 0) return;
+    hipLaunchKernelGGL(pny_dw_reduce_kernel, dim3((unsigned)((max_elems + 255) / 256), n_targets), dim3(256), 0, st,
+                       targets_dev, partial, bias_partial, accumulate);
+}
+
+// ---------------------------------------------------------------------------------------------- composite backward
+// Reverse of composite_kernel (render_kernels.hip; reference nerf.py:184-188, 229-250).  One wavefront per ray.
+//   alpha_k = 1 - exp(-delta_k s_k), s_k = relu(sigma_k [+ noise]); A_k = 1 - alpha_k + 1e-10; T_k = prod_{j<k} A_j; w_k = alpha_k T_k
+//   G_k = dL/dw_k = sum_c g_rgb_c (c_kc - [white]) + g_depth z_k + g_w_k
+//   dL/dalpha_k = G_k T_k - (sum_{j>k} G_j w_j) / A_k      (cumprod backward for non-zero factors, as autograd computes it)
+//   dL/ds_k = dL/dalpha_k delta_k exp(-delta_k s_k);  dL/ddelta_k = dL/dalpha_k s_k exp(-delta_k s_k)
+// Outputs: d_samp (n,K,4) = gradient w.r.t. the model's per-sample outputs [rgb (after sigmoid), sigma (after relu)];
+// d_z (n,K) (optional) = gradient w.r.t. the sample depths through delta and through depth = sum w z.
+__device__ __forceinline__ float bwd_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restrict__ rays, const float* __restrict__ z,
+                                                            const float* __restrict__ samp, const float* __restrict__ noise,
+                                                            long long n, int K, int white, const float* __restrict__ g_rgb,
+                                                            const float* __restrict__ g_depth, const float* __restrict__ g_w,
+                                                            float* __restrict__ d_samp, float* __restrict__ d_z) {
+    extern __shared__ float cb_lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long ray = (long long)blockIdx.x * 4 + wv;
+    if (ray >= n) return;
+    float* Tw = cb_lds + (size_t)wv * 2 * K;  // T_k, later w_k
+    float* Ad = Tw + K;                       // alpha_k, later dL/ddelta_k
+    const float far = rays[ray * 8 + 7];
+    const float* zr = z + ray * K;
+    const float4* sr = reinterpret_cast<const float4*>(samp) + ray * K;
+    const float gr = g_rgb ? g_rgb[ray * 3 + 0] : 0.f, gg = g_rgb ? g_rgb[ray * 3 + 1] : 0.f,
+                gb = g_rgb ? g_rgb[ray * 3 + 2] : 0.f;
+    const float gd = g_depth ? g_depth[ray] : 0.f;
+    const float wsub = white ? (gr + gg + gb) : 0.f;  // rgb + 1 - sum(w): every w_k carries -sum_c g_rgb_c
+
+    float carry = 1.0f;
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        const int k = k0 + lane;
+        const bool on = k < K;
+        float alpha = 0.f;
+        if (on) {
+            const float zk = zr[k];
+            const float znext = (k + 1 < K) ? zr[k + 1] : far;
+            float sg = sr[k].w;
+            if (noise) sg += noise[ray * K + k];
+            alpha = 1.0f - expf(-(znext - zk) * fmaxf(sg, 0.f));
+        }
+        float pprod = on ? (1.0f - alpha + 1e-10f) : 1.0f;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float up = __shfl_up(pprod, o, 64);
+            if (lane >= o) pprod *= up;
+        }
+        float excl = __shfl_up(pprod, 1, 64);
+        if (lane == 0) excl = 1.0f;
+        if (on) {
+            Tw[k] = carry * excl;
+            Ad[k] = alpha;
+        }
+        carry *= __shfl(pprod, 63, 64);
+    }
+    // reverse pass: suffix sums of G_j w_j
+    float suffix = 0.f;  // sum over samples beyond the current chunk
+    const int nchunk = (K + 63) / 64;
+    for (int c = nchunk - 1; c >= 0; --c) {
+        const int k = c * 64 + lane;
+        const bool on = k < K;
+        float G = 0.f, w = 0.f, T = 0.f, alpha = 0.f, zk = 0.f, delta = 0.f, s = 0.f, sg_eff = 0.f;
+        float4 sm = {0.f, 0.f, 0.f, 0.f};
+        if (on) {
+            zk = zr[k];
+            const float znext = (k + 1 < K) ? zr[k + 1] : far;
+            delta = znext - zk;
+            sm = sr[k];
+            sg_eff = sm.w + (noise ? noise[ray * K + k] : 0.f);
+            s = fmaxf(sg_eff, 0.f);
+            T = Tw[k];
+            alpha = Ad[k];
+            w = alpha * T;
+            G = gr * sm.x + gg * sm.y + gb * sm.z - wsub + gd * zk + (g_w ? g_w[ray * K + k] : 0.f);
+        }
+        // inclusive suffix scan over the lanes of the chunk
+        float incl = G * w;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float dn = __shfl_down(incl, o, 64);
+            if (lane + o < 64) incl += dn;
+        }
+        const float excl = incl - G * w + suffix;   // sum_{j > k} G_j w_j
+        suffix += __shfl(incl, 0, 64);
+        if (on) {
+            const float A = 1.0f - alpha + 1e-10f;
+            const float dalpha = G * T - excl / A;
+            const float e = expf(-delta * s);
+            const float ds = dalpha * (delta * e);
+            const float dsig = sg_eff > 0.f ? ds : 0.f;
+            reinterpret_cast<float4*>(d_samp)[ray * K + k] = make_float4(gr * w, gg * w, gb * w, dsig);
+            Tw[k] = w;
+            Ad[k] = dalpha * (s * e);   // dL/ddelta_k
+        }
+    }
+    if (d_z) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int k = lane; k < K; k += 64) d_z[ray * K + k] = gd * Tw[k] + (k > 0 ? Ad[k - 1] : 0.f) - Ad[k];
+    }
+}
+
+void launch_composite_bwd(const float* rays, const float* z, const float* samp, const float* noise, long long n, int k,
+                          int white, const float* g_rgb, const float* g_depth, const float* g_w, float* d_samp, float* d_z,
+                          hipStream_t st) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), (size_t)4 * 2 * k * sizeof(float), st,
+                       rays, z, samp, noise, n, k, white, g_rgb, g_depth, g_w, d_samp, d_z);
+}
+
+}  // namespace pny

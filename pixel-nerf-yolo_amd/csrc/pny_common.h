@@ -37,6 +37,24 @@ struct MlpWeights {
     const float* b_out;
 };
 
+// Training stash (64-sample tiles; every tensor slot is [feature/4][64 samples] float4, i.e. the LDS B-operand layout):
+//   X record of a tile  = NS views x { x_in (16 rows), z (L/4 rows), per view block b: relu(h_in(b)), relu(net(b)) }
+//                         + post part { per post block: relu(h_in(b)), relu(net(b)) ; relu(h_top) }
+//   dY record of a tile = NS views x { per view block b: dnet(b), dh_in(b) }
+//                         + post part { d_raw (16 rows), dh_top, per post block b: dnet(b), dh_in(b) }
+//     (dh_in of the first post-combine block holds dhm = dh / NS, the gradient every view's last block receives; when
+//      there is no post-combine block dhm IS dh_top)
+// Offsets are in floats.  SLOT = 64 * 512 floats.
+struct StashLayout {
+    long long x_tile, dy_tile;       // record strides
+    int x_view, x_in, x_z, x_act;    // view stride; offsets inside a view
+    int x_post;                      // offset of the post part inside a record
+    int dy_view;                     // view stride (offset of a view's first slot is v * dy_view)
+    int dy_post;                     // offset of the post part: d_raw, dh_top, then the post blocks
+};
+constexpr int STASH_SLOT = 64 * HID;
+constexpr int STASH_SMALL = 64 * D_IN_PAD;  // 16-row slots: x_in, d_raw
+
 struct MlpArgs {
     MlpWeights w;
     const float* w_base;  // the allocation all packed layers of `w` live in (raw-buffer addressing, mlp.hip)
@@ -64,14 +82,68 @@ struct MlpArgs {
     float freq_factor;
     float sx, sy;     // latent_scaling / image_size (reference encoder.py:97)
     int n_tiles;
+    // training: activation stash written by the STASH instantiation (launch_mlp_stash); null otherwise
+    float* stash_x;
+    StashLayout lay;
     // Source-view cameras travel in the kernel-argument segment (NS entries used; 64 B each): a launch carries its own
     // copy, so pny_scene_set_cameras touches no device memory (no copy, no synchronisation, no stream to order against)
     Cam cams[MAX_VIEWS];
 };
 
+// ---- backward pass (mlp_bwd.hip)
+struct BwdArgs {
+    // TRANSPOSED packed weights (A operands of dX^T = W^T dY^T), inside the model's packed blob
+    const float* wT_out;              // lin_out^T: 512 x d_out, K padded to D_IN_PAD
+    const float* wT_fc0[MAX_BLOCKS];
+    const float* wT_fc1[MAX_BLOCKS];
+    const float* w_base;
+    unsigned w_bytes;
+    const float* x_stash;             // written by the STASH forward
+    float* dy_stash;
+    StashLayout lay;
+    const float* out;                 // (n_points, d_out) forward outputs (after the head)
+    const float* d_out_grad;          // (n_points, d_out) gradient w.r.t. those outputs
+    long long n_points;
+    int n_tiles;
+    int NS, n_blocks, combine_layer, d_out, yolo;
+};
+// One weight-gradient GEMM: C[a_rows][x_cols] = sum over (tile, view) dY_slot^T X_slot.
+struct DwJob {
+    long long a_off, x_off;   // slot offsets inside a dY / X record (floats), view 0
+    int a_view, x_view;       // per-view strides in floats (0: the slot exists once per tile)
+    int n_views;              // views reduced over
+    int a_rows, x_cols;       // rows of C (512, or 64 for lin_out) and columns (512, 64 for lin_in, L for lin_z)
+};
+// One workgroup's share: output tile (mt, nt) of 256 x 256 over the (tile, view) range [tv_lo, tv_hi).
+struct DwItem {
+    int job, mt, nt, tv_lo, tv_hi;
+    long long part_off;       // float offset of the split's [a_rows][x_cols] block in the partial buffer
+    long long bias_off;       // float offset of the split's [a_rows] block in the bias partial buffer
+};
+// Where a job's reduced result goes: weight (rows x cols valid, row-major, the state_dict layout) and up to two bias
+// vectors that share the column sum (lin_z bias folded next to the preceding layer's).
+struct DwTarget {
+    float* w;
+    float* b0;
+    float* b1;
+    int rows, cols;           // valid extent written to w
+    int prows, pcols;         // extent of one split's partial block
+    int splits;
+    long long part_off, bias_off;
+};
+void launch_mlp_bwd(const BwdArgs& a, int grid, hipStream_t st);
+void launch_dw_gemm(const DwJob* jobs_dev, const DwItem* items_dev, int n_items, const float* x_stash, const float* dy_stash,
+                    long long x_tile, long long dy_tile, float* partial, float* bias_partial, hipStream_t st);
+void launch_dw_reduce(const DwTarget* targets_dev, int n_targets, long long max_elems, const float* partial,
+                      const float* bias_partial, int accumulate, hipStream_t st);
+void launch_composite_bwd(const float* rays, const float* z, const float* samp, const float* noise, long long n, int k,
+                          int white, const float* g_rgb, const float* g_depth, const float* g_w, float* d_samp, float* d_z,
+                          hipStream_t st);
+
 enum { MLP_8x64 = 0, MLP_16x64 = 1, MLP_8x32 = 2 };  // kernel shapes (mlp.hip Cfg)
 int mlp_pick_variant(long long n_points);           // shape for a launch of n_points samples
 void launch_mlp(const MlpArgs& a, int variant, int grid, hipStream_t st);
+void launch_mlp_stash(const MlpArgs& a, int grid, hipStream_t st);  // 8x64 shape, reference op order, writes a.stash_x
 int mlp_max_grid(int variant);      // resident workgroups = persistent grid size
 int mlp_tile_samples(int variant);  // samples per workgroup tile (32 or 64)
 size_t mlp_scratch_floats();

@@ -1,0 +1,318 @@
+// Training entry points of libpnyolo.so (include/pnyolo.h, "backward" section): the gradient the reference obtains with
+// loss.backward() through NeRFRenderer.forward / PixelNeRFNet.forward (reference train/trainlib/PixelNerfTrainer.py:133-156,
+// src/render/nerf.py:169-309, src/model/resnetfc.py:134-186).  Host-side C++: stash sizing, the weight-gradient GEMM
+// work list and the launch sequence; all arithmetic is in mlp.hip (STASH forward) and mlp_bwd.hip.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "api_internal.h"
+
+using namespace pny;
+
+namespace {
+
+struct TrainPlan {
+    StashLayout lay;
+    std::vector<DwJob> jobs;
+    std::vector<DwTarget> targets;  // same order as jobs
+};
+
+float* grad_of(const pny_model* m, const std::string& name) {
+    auto it = m->grads.find(name);
+    return it == m->grads.end() ? nullptr : it->second;
+}
+
+// Stash layout and the list of weight-gradient GEMMs of one MLP (pny_common.h StashLayout for the slot order).
+TrainPlan build_plan(const pny_model* m, int ns, int L, const std::string& pre) {
+    const pny_model_desc& d = m->desc;
+    const int nb = d.n_blocks, nvb = view_blocks(d), npost = nb - nvb;
+    const int d_in = 3 + 6 * d.num_freqs + 3;
+    TrainPlan p;
+    StashLayout& l = p.lay;
+    l.x_in = 0;
+    l.x_z = STASH_SMALL;
+    l.x_act = STASH_SMALL + L * 64;
+    l.x_view = l.x_act + 2 * nvb * STASH_SLOT;
+    l.x_post = ns * l.x_view;
+    l.x_tile = (long long)l.x_post + (long long)(2 * npost + 1) * STASH_SLOT;
+    l.dy_view = 2 * nvb * STASH_SLOT;
+    l.dy_post = ns * l.dy_view;
+    l.dy_tile = (long long)l.dy_post + STASH_SMALL + (long long)(1 + 2 * npost) * STASH_SLOT;
+    auto xact = [&](int i) { return (long long)l.x_act + (long long)i * STASH_SLOT; };
+    auto xpost = [&](int i) { return (long long)l.x_post + (long long)i * STASH_SLOT; };
+    auto dyv = [&](int i) { return (long long)i * STASH_SLOT; };
+    const long long draw = l.dy_post;
+    auto dypost = [&](int i) { return (long long)l.dy_post + STASH_SMALL + (long long)i * STASH_SLOT; };
+    const long long dhm = npost > 0 ? dypost(2) : dypost(0);
+    auto add = [&](long long a_off, int a_view, int a_rows, long long x_off, int x_view, int x_cols, int n_views,
+                   const std::string& wname, int rows_valid, int cols_valid, const std::string& b0, const std::string& b1) {
+        DwJob j;
+        j.a_off = a_off;
+        j.a_view = a_view;
+        j.a_rows = a_rows;
+        j.x_off = x_off;
+        j.x_view = x_view;
+        j.x_cols = x_cols;
+        j.n_views = n_views;
+        DwTarget t;
+        memset(&t, 0, sizeof(t));
+        t.w = grad_of(m, wname);
+        t.b0 = b0.empty() ? nullptr : grad_of(m, b0);
+        t.b1 = b1.empty() ? nullptr : grad_of(m, b1);
+        t.rows = rows_valid;
+        t.cols = cols_valid;
+        t.prows = a_rows;
+        t.pcols = x_cols;
+        p.jobs.push_back(j);
+        p.targets.push_back(t);
+    };
+    auto blk = [&](int b) { return pre + "blocks." + std::to_string(b); };
+    auto lz = [&](int b) { return pre + "lin_z." + std::to_string(b); };
+    // lin_out: dY = d_raw (16-row slot, d_out rows valid), X = relu(h_top)
+    add(draw, 0, D_IN_PAD, xpost(2 * npost), 0, HID, 1, pre + "lin_out.weight", d.d_out, HID, pre + "lin_out.bias", "");
+    for (int b = nvb; b < nb; ++b) {  // post-combine blocks
+        const int i = b - nvb;
+        add(dypost(1 + 2 * i), 0, HID, xpost(2 * i), 0, HID, 1, blk(b) + ".fc_0.weight", HID, HID, blk(b) + ".fc_0.bias", "");
+        add(b == nb - 1 ? dypost(0) : dypost(2 + 2 * (i + 1)), 0, HID, xpost(2 * i + 1), 0, HID, 1, blk(b) + ".fc_1.weight", HID, HID,
+            blk(b) + ".fc_1.bias", "");
+    }
+    for (int b = 0; b < nvb; ++b) {  // per-view blocks: reduce over the views too
+        add(dyv(2 * b), l.dy_view, HID, xact(2 * b), l.x_view, HID, ns, blk(b) + ".fc_0.weight", HID, HID, blk(b) + ".fc_0.bias", "");
+        const bool last = b == nvb - 1;
+        add(last ? dhm : dyv(2 * (b + 1) + 1), last ? 0 : l.dy_view, HID, xact(2 * b + 1), l.x_view, HID, ns,
+            blk(b) + ".fc_1.weight", HID, HID, blk(b) + ".fc_1.bias", last ? std::string() : lz(b + 1) + ".bias");
+        add(dyv(2 * b + 1), l.dy_view, HID, l.x_z, l.x_view, L, ns, lz(b) + ".weight", HID, L, "", "");
+    }
+    // lin_in: dY = the gradient at the first block's entry (dhm when the mean follows lin_in directly)
+    add(nvb > 0 ? dyv(1) : dhm, nvb > 0 ? l.dy_view : 0, HID, l.x_in, l.x_view, D_IN_PAD, ns, pre + "lin_in.weight", HID, d_in,
+        pre + "lin_in.bias", nvb > 0 ? lz(0) + ".bias" : std::string());
+    return p;
+}
+
+// Split every job's (tile, view) range over workgroups so that the grid has ~4 workgroups per CU with equal work.
+void build_items(TrainPlan& p, int n_tiles, int cus, std::vector<DwItem>& items, long long* part_floats, long long* bias_floats) {
+    items.clear();
+    double total = 0.0;
+    std::vector<int> otiles(p.jobs.size());
+    for (size_t j = 0; j < p.jobs.size(); ++j) {
+        const DwJob& jb = p.jobs[j];
+        otiles[j] = ((jb.a_rows + 255) / 256) * ((jb.x_cols + 255) / 256);
+        total += (double)otiles[j] * jb.n_views * n_tiles;
+    }
+    const double per_item = std::max(1.0, total / (4.0 * cus));
+    long long poff = 0, boff = 0;
+    for (size_t j = 0; j < p.jobs.size(); ++j) {
+        const DwJob& jb = p.jobs[j];
+        const int tv = jb.n_views * n_tiles;
+        int splits = (int)std::lround((double)tv / per_item);
+        splits = std::max(1, std::min(splits, tv));
+        const int per = (tv + splits - 1) / splits;
+        splits = (tv + per - 1) / per;
+        DwTarget& t = p.targets[j];
+        t.splits = splits;
+        t.part_off = poff;
+        t.bias_off = boff;
+        const int mts = (jb.a_rows + 255) / 256, nts = (jb.x_cols + 255) / 256;
+        for (int sp = 0; sp < splits; ++sp)
+            for (int mt = 0; mt < mts; ++mt)
+                for (int nt = 0; nt < nts; ++nt) {
+                    DwItem it;
+                    it.job = (int)j;
+                    it.mt = mt;
+                    it.nt = nt;
+                    it.tv_lo = sp * per;
+                    it.tv_hi = std::min(tv, (sp + 1) * per);
+                    it.part_off = poff + (long long)sp * jb.a_rows * jb.x_cols;
+                    it.bias_off = boff + (long long)sp * jb.a_rows;
+                    items.push_back(it);
+                }
+        poff += (long long)splits * jb.a_rows * jb.x_cols;
+        boff += (long long)splits * jb.a_rows;
+    }
+    // longest first: the tail of the grid is then made of short items
+    std::stable_sort(items.begin(), items.end(), [](const DwItem& a, const DwItem& b) { return (a.tv_hi - a.tv_lo) > (b.tv_hi - b.tv_lo); });
+    *part_floats = poff;
+    *bias_floats = boff;
+}
+
+size_t stash_budget_bytes() {
+    static size_t v = 0;
+    if (!v) {
+        v = (size_t)16 << 30;  // both stashes together; PNYOLO_STASH_GB overrides
+        if (const char* e = getenv("PNYOLO_STASH_GB")) {
+            const double g = atof(e);
+            if (g > 0.01) v = (size_t)(g * (double)((size_t)1 << 30));
+        }
+    }
+    return v;
+}
+
+// Backward of one MLP evaluation over n_points query points (mode 0: xyz / dirs; mode 1: rays + z with K samples per
+// ray): d_out (n_points, d_out) -> bound parameter gradients.  Points are processed in chunks that fit the stash.
+int mlp_backward(pny_scene* s, int mode, const float* xyz, const float* dirs, const float* rays, const float* z, int K,
+                 long long n_points, int coarse, const float* d_out, int accumulate, hipStream_t st) {
+    if (n_points == 0) return 0;
+    pny_model* m = s->m;
+    const pny_model_desc& d = m->desc;
+    const bool fine_w = !(coarse || !d.has_fine || !m->use_fine);
+    const std::string pre = fine_w ? "mlp_fine." : "mlp_coarse.";
+    TrainPlan plan = build_plan(m, s->ns, s->L, pre);
+    const size_t tile_bytes = (size_t)(plan.lay.x_tile + plan.lay.dy_tile) * sizeof(float);
+    long long max_tiles = (long long)(stash_budget_bytes() / tile_bytes);
+    if (max_tiles < 1) return fail(PNY_ERR_ARG, "stash budget smaller than one tile");
+    // chunk boundaries on whole rays (mode 1) so that sample -> ray indexing stays local to the chunk
+    const long long unit = mode == 1 ? K : 1;
+    long long chunk_pts = std::min(n_points, max_tiles * 64);
+    chunk_pts = std::max(unit, chunk_pts / unit * unit);
+    const int cus = mlp_max_grid(MLP_8x64);
+    int rc;
+    const long long chunk_tiles_max = (chunk_pts + 63) / 64;
+    if ((rc = s->x_stash.reserve((size_t)chunk_tiles_max * plan.lay.x_tile * sizeof(float)))) return rc;
+    if ((rc = s->dy_stash.reserve((size_t)chunk_tiles_max * plan.lay.dy_tile * sizeof(float)))) return rc;
+    if ((rc = s->out_tmp.reserve((size_t)chunk_pts * d.d_out * sizeof(float)))) return rc;
+    std::vector<DwItem> items;
+    for (long long p0 = 0; p0 < n_points; p0 += chunk_pts) {
+        const long long np = std::min(chunk_pts, n_points - p0);
+        const int n_tiles = (int)((np + 63) / 64);
+        // 1. forward in the reference's operation order, stashing every GEMM's B operand
+        MlpArgs a;
+        if ((rc = fill_mlp_args(s, mode, mode == 0 ? xyz + 3 * p0 : nullptr, mode == 0 ? dirs + 3 * p0 : nullptr,
+                                mode == 1 ? rays + (p0 / K) * 8 : nullptr, mode == 1 ? z + p0 : nullptr, K, np, coarse,
+                                s->out_tmp.f(), &a)))
+            return rc;
+        a.stash_x = s->x_stash.f();
+        a.lay = plan.lay;
+        const int grid = std::min(cus, n_tiles);
+        launch_mlp_stash(a, grid, st);
+        PNY_HIP(hipGetLastError());
+        // 2. dX chain
+        const MlpWeightsT& wt = fine_w ? m->fine_t : m->coarse_t;
+        BwdArgs b;
+        memset(&b, 0, sizeof(b));
+        b.wT_out = wt.wT_out;
+        for (int i = 0; i < d.n_blocks; ++i) {
+            b.wT_fc0[i] = wt.wT_fc0[i];
+            b.wT_fc1[i] = wt.wT_fc1[i];
+        }
+        b.w_base = m->packed.f();
+        b.w_bytes = (unsigned)m->packed.bytes;
+        b.x_stash = s->x_stash.f();
+        b.dy_stash = s->dy_stash.f();
+        b.lay = plan.lay;
+        b.out = s->out_tmp.f();
+        b.d_out_grad = d_out + p0 * d.d_out;
+        b.n_points = np;
+        b.n_tiles = n_tiles;
+        b.NS = s->ns;
+        b.n_blocks = d.n_blocks;
+        b.combine_layer = d.combine_layer;
+        b.d_out = d.d_out;
+        b.yolo = d.yolo;
+        launch_mlp_bwd(b, grid, st);
+        PNY_HIP(hipGetLastError());
+        // 3. weight-gradient GEMMs over the two stashes + deterministic split reduction into the bound gradients
+        long long part_floats = 0, bias_floats = 0;
+        build_items(plan, n_tiles, cus, items, &part_floats, &bias_floats);
+        if ((rc = s->dw_partial.reserve((size_t)part_floats * sizeof(float)))) return rc;
+        if ((rc = s->dw_bias.reserve((size_t)bias_floats * sizeof(float)))) return rc;
+        const size_t jb_bytes = plan.jobs.size() * sizeof(DwJob), it_bytes = items.size() * sizeof(DwItem),
+                     tg_bytes = plan.targets.size() * sizeof(DwTarget);
+        const size_t o_items = (jb_bytes + 255) & ~(size_t)255, o_targets = o_items + ((it_bytes + 255) & ~(size_t)255);
+        if ((rc = s->dw_tables.reserve(o_targets + tg_bytes))) return rc;
+        // the tables are small (KBs) and change with the chunk's tile count: staged with stream-ordered copies from a
+        // host block that lives until the copies have executed (the scene keeps it)
+        s->table_host.resize(o_targets + tg_bytes);
+        memcpy(s->table_host.data(), plan.jobs.data(), jb_bytes);
+        memcpy(s->table_host.data() + o_items, items.data(), it_bytes);
+        memcpy(s->table_host.data() + o_targets, plan.targets.data(), tg_bytes);
+        PNY_HIP(hipStreamSynchronize(st));  // (v1) the previous chunk's kernels still read the tables
+        PNY_HIP(hipMemcpyAsync(s->dw_tables.p, s->table_host.data(), o_targets + tg_bytes, hipMemcpyHostToDevice, st));
+        char* tb = reinterpret_cast<char*>(s->dw_tables.p);
+        launch_dw_gemm(reinterpret_cast<const DwJob*>(tb), reinterpret_cast<const DwItem*>(tb + o_items), (int)items.size(),
+                       s->x_stash.f(), s->dy_stash.f(), plan.lay.x_tile, plan.lay.dy_tile, s->dw_partial.f(), s->dw_bias.f(), st);
+        PNY_HIP(hipGetLastError());
+        long long max_elems = 0;
+        for (const DwTarget& t : plan.targets) max_elems = std::max(max_elems, (long long)t.rows * t.cols + t.rows);
+        launch_dw_reduce(reinterpret_cast<const DwTarget*>(tb + o_targets), (int)plan.targets.size(), max_elems,
+                         s->dw_partial.f(), s->dw_bias.f(), (accumulate || p0 > 0) ? 1 : 0, st);
+        PNY_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pny_model_bind_grad(pny_model* m, const char* name, float* grad_dev) {
+    if (!m || !name) return fail(PNY_ERR_ARG, "pny_model_bind_grad: null argument");
+    if (grad_dev)
+        m->grads[name] = grad_dev;
+    else
+        m->grads.erase(name);
+    return PNY_OK;
+}
+
+int pny_query_backward(pny_scene* s, const float* xyz_dev, const float* viewdirs_dev, int64_t n, int coarse,
+                       const float* d_out_dev, int accumulate, pny_stream stream) {
+    int rc;
+    if ((rc = check_ready(s, "pny_query_backward"))) return rc;
+    if (n < 0 || (n > 0 && (!xyz_dev || !viewdirs_dev || !d_out_dev))) return fail(PNY_ERR_ARG, "pny_query_backward: bad argument");
+    PNY_HIP(hipSetDevice(s->m->desc.device));
+    if ((rc = enter_stream(s, (hipStream_t)stream))) return rc;
+    return mlp_backward(s, 0, xyz_dev, viewdirs_dev, nullptr, nullptr, 1, n, coarse, d_out_dev, accumulate, (hipStream_t)stream);
+}
+
+int pny_composite_backward(const float* rays_dev, const float* z_dev, const float* sample_dev, int64_t n, int k, int white_bkgd,
+                           const float* g_rgb_dev, const float* g_depth_dev, const float* g_weights_dev, float* d_sample_dev,
+                           float* d_z_dev, pny_stream stream) {
+    if (n < 0 || k < 1 || (n > 0 && (!rays_dev || !z_dev || !sample_dev || !d_sample_dev)))
+        return fail(PNY_ERR_ARG, "pny_composite_backward: bad argument");
+    if ((size_t)4 * 2 * k * sizeof(float) > 64 * 1024) return fail(PNY_ERR_ARG, "pny_composite_backward: too many samples per ray");
+    launch_composite_bwd(rays_dev, z_dev, sample_dev, nullptr, n, k, white_bkgd, g_rgb_dev, g_depth_dev, g_weights_dev, d_sample_dev,
+                         d_z_dev, (hipStream_t)stream);
+    PNY_HIP(hipGetLastError());
+    return PNY_OK;
+}
+
+int pny_render_backward(pny_scene* s, const float* rays_dev, int64_t n, const pny_render_opts* o, const pny_render_saved* sv,
+                        const pny_render_grads* g, int accumulate, pny_stream stream) {
+    int rc;
+    if ((rc = check_ready(s, "pny_render_backward"))) return rc;
+    if (!o || !sv || !g || n < 0 || (n > 0 && !rays_dev)) return fail(PNY_ERR_ARG, "pny_render_backward: bad argument");
+    if (s->m->desc.yolo || s->m->desc.d_out != 4) return fail(PNY_ERR_ARG, "pny_render_backward: model is in YOLO mode");
+    if (n == 0) return PNY_OK;
+    const int kc = o->n_coarse, kt = o->n_coarse + o->n_fine;
+    if (!sv->z_coarse || !sv->sample_coarse || (o->n_fine > 0 && (!sv->z_fine || !sv->sample_fine)))
+        return fail(PNY_ERR_ARG, "pny_render_backward: the forward call's z / per-sample outputs are required");
+    if ((size_t)4 * 2 * kt * sizeof(float) > 64 * 1024) return fail(PNY_ERR_ARG, "pny_render_backward: too many samples per ray");
+    PNY_HIP(hipSetDevice(s->m->desc.device));
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = enter_stream(s, st))) return rc;
+    if ((rc = s->d_samp.reserve((size_t)n * kt * 4 * sizeof(float)))) return rc;
+    const bool same_mlp = !s->m->desc.has_fine || !s->m->use_fine;  // both passes differentiate mlp_coarse
+    bool first = true;
+    const bool any_f = o->n_fine > 0 && (g->rgb_fine || g->depth_fine || g->weights_fine);
+    const bool any_c = g->rgb_coarse || g->depth_coarse || g->weights_coarse;
+    if (any_f) {
+        launch_composite_bwd(rays_dev, sv->z_fine, sv->sample_fine, nullptr, n, kt, o->white_bkgd, g->rgb_fine, g->depth_fine,
+                             g->weights_fine, s->d_samp.f(), nullptr, st);
+        PNY_HIP(hipGetLastError());
+        if ((rc = mlp_backward(s, 1, nullptr, nullptr, rays_dev, sv->z_fine, kt, (long long)n * kt, 0, s->d_samp.f(), accumulate, st)))
+            return rc;
+        first = false;
+    }
+    if (any_c) {
+        launch_composite_bwd(rays_dev, sv->z_coarse, sv->sample_coarse, nullptr, n, kc, o->white_bkgd, g->rgb_coarse, g->depth_coarse,
+                             g->weights_coarse, s->d_samp.f(), nullptr, st);
+        PNY_HIP(hipGetLastError());
+        if ((rc = mlp_backward(s, 1, nullptr, nullptr, rays_dev, sv->z_coarse, kc, (long long)n * kc, 1, s->d_samp.f(),
+                               (accumulate || (same_mlp && !first)) ? 1 : 0, st)))
+            return rc;
+    }
+    return PNY_OK;
+}
+
+}  // extern "C"

@@ -41,6 +41,15 @@ class RenderOut(C.Structure):
         "z_coarse", "z_fine", "sample_coarse", "sample_fine")]
 
 
+class RenderSaved(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("z_coarse", "sample_coarse", "z_fine", "sample_fine")]
+
+
+class RenderGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("rgb_coarse", "depth_coarse", "weights_coarse", "rgb_fine", "depth_fine",
+                                          "weights_fine")]
+
+
 # name -> (restype, argtypes); every symbol include/pnyolo.h declares
 SIGNATURES = {
     "pny_version": (C.c_int, []),
@@ -86,10 +95,16 @@ SIGNATURES = {
     "pny_scene_last_mlp_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                            C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pny_scene_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "pny_model_bind_grad": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p]),
+    "pny_query_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "pny_composite_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pny_render_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(RenderOpts), C.POINTER(RenderSaved),
+                                      C.POINTER(RenderGrads), C.c_int, C.c_void_p]),
 }
 
 _lib = None
-ABI_VERSION = 4
+ABI_VERSION = 5
 PROJECTION = {"off": 0, "on": 1, "auto": 2}
 
 

@@ -359,6 +359,42 @@ class PixelNeRFNet(nn.Module):
             return dict(flops=fl, flops_reference=ref, kernel_ms=ms, launches=n, projected=proj)
         return fl, ms, n
 
+    # ---------------------------------------------------------------- training plumbing
+    def trainable_mlp_parameters(self):
+        """[(state_dict name, Parameter)] of the MLP parameters that require grad, in a fixed order."""
+        out = []
+        for pre, mlp in (("mlp_coarse.", self.mlp_coarse), ("mlp_fine.", self.mlp_fine)):
+            if mlp is not None:
+                out += [(pre + k, p) for k, p in mlp.named_parameters() if p.requires_grad]
+        return out
+
+    def check_differentiable(self):
+        """The backward pass covers the MLPs; the encoder must be frozen (reference: --freeze_enc / stop_encoder_grad,
+        train/train.py:70-73, models.py:33-35)."""
+        if not self.stop_encoder_grad and any(p.requires_grad for p in self.encoder.parameters()):
+            raise NotImplementedError(
+                "libpnyolo differentiates the MLPs only: freeze the encoder (make_model(conf, stop_encoder_grad=True) "
+                "or requires_grad_(False) on net.encoder, as the reference's --freeze_enc does)")
+
+    def bind_mlp_grads(self):
+        """Fresh zeroed gradient buffers for trainable_mlp_parameters(), bound to the native model by name
+        (pny_model_bind_grad); returns them in the same order."""
+        self._sync()
+        L = _lib.load()
+        grads = []
+        for name, p in self.trainable_mlp_parameters():
+            g = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.contiguous_format)
+            check(L.pny_model_bind_grad(self._h_model, name.encode(), ptr(g)))
+            grads.append(g)
+        self._bound_grads = grads   # keep the buffers alive while they are bound
+        return grads
+
+    def invalidate_weights(self):
+        """Force a re-upload of the parameters at the next call.  Needed after writes that PyTorch does not version:
+        ``p.data.copy_(w)`` / ``p.data.zero_()`` leave ``p._version`` and ``data_ptr()`` unchanged."""
+        self._synced_key = None
+        return self
+
     # ---------------------------------------------------------------- reference API
     def encode(self, images, poses, focal, z_bounds=None, c=None, latent=None):
         """
@@ -442,9 +478,14 @@ class PixelNeRFNet(nn.Module):
         Predict (r, g, b, sigma) at world space points xyz (after encode()).
         :param xyz (SB, B, 3);  :param viewdirs (SB, B, 3)  ->  (SB, B, d_out)
         """
-        if torch.is_grad_enabled() and (xyz.requires_grad or self.training):
-            raise RuntimeError("libpnyolo is forward-only (SURVEY.md 8f): call it in eval() mode or under "
-                               "torch.no_grad(); gradients would silently be dropped otherwise")
+        if torch.is_grad_enabled() and xyz.requires_grad:
+            raise RuntimeError("libpnyolo does not differentiate w.r.t. the query points: detach xyz")
+        if torch.is_grad_enabled() and self.trainable_mlp_parameters():
+            self.check_differentiable()
+            return _QueryFunction.apply(self, xyz, bool(coarse), viewdirs, *[p for _, p in self.trainable_mlp_parameters()])
+        return self._query(xyz, coarse, viewdirs)
+
+    def _query(self, xyz, coarse, viewdirs):
         self._sync()
         L = _lib.load()
         dev = self._device()
@@ -499,6 +540,33 @@ class PixelNeRFNet(nn.Module):
         if epochNum == "":
             torch.save(self.state_dict(), ckpt_path)
         return self
+
+
+class _QueryFunction(torch.autograd.Function):
+    """PixelNeRFNet.forward under autograd: pny_query forward, pny_query_backward into bound gradient buffers."""
+
+    @staticmethod
+    def forward(ctx, net, xyz, coarse, viewdirs, *params):
+        out = net._query(xyz, coarse, viewdirs)
+        dev = net._device()
+        ctx.net, ctx.coarse = net, coarse
+        ctx.xyz = xyz.detach().to(dev, torch.float32).contiguous()
+        ctx.dirs = viewdirs.detach().to(dev, torch.float32).reshape(ctx.xyz.shape).contiguous()
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        net = ctx.net
+        L = _lib.load()
+        dev = net._device()
+        grads = net.bind_mlp_grads()
+        g_out = g_out.detach().to(dev, torch.float32).contiguous()
+        use_coarse = bool(ctx.coarse) or net.mlp_fine is None
+        st = stream_of(dev)
+        for sb in range(ctx.xyz.shape[0]):
+            check(L.pny_query_backward(net._scene(sb), ptr(ctx.xyz[sb]), ptr(ctx.dirs[sb]), ctx.xyz.shape[1], int(use_coarse),
+                                       ptr(g_out[sb]), 1, st))
+        return (None, None, None, None) + tuple(grads)
 
 
 def make_model(conf, *args, **kwargs):

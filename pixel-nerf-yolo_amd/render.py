@@ -41,6 +41,52 @@ class _RenderWrapper(torch.nn.Module):
         return outputs  # plain nested dict, as DotMap.toDict() in the reference
 
 
+class _RenderFunction(torch.autograd.Function):
+    """NeRFRenderer.forward under autograd: forward = the ordinary pny_render (with its z / per-sample outputs kept),
+    backward = pny_render_backward per scene, which accumulates into gradient buffers bound to the MLP parameters."""
+
+    @staticmethod
+    def forward(ctx, renderer, model, rays, has_fine, n_params, *params):
+        res, saved = renderer._render(model, rays, want_weights=True, save=True)
+        ctx.renderer, ctx.model, ctx.saved, ctx.has_fine = renderer, model, saved, has_fine
+        ctx.white_bkgd = bool(renderer.white_bkgd)
+        ctx.set_materialize_grads(False)
+        outs = [res["coarse"]["rgb"], res["coarse"]["depth"], res["coarse"]["weights"]]
+        if has_fine:
+            outs += [res["fine"]["rgb"], res["fine"]["depth"], res["fine"]["weights"]]
+        else:
+            outs += [rays.new_zeros(0), rays.new_zeros(0), rays.new_zeros(0)]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g_rgb_c, g_depth_c, g_w_c, g_rgb_f, g_depth_f, g_w_f):
+        model, sv = ctx.model, ctx.saved
+        L = _lib.load()
+        dev = model._device()
+        grads = model.bind_mlp_grads()            # zeroed fp32 buffers, one per trainable MLP parameter, bound by name
+        st = stream_of(dev)
+        SB, B = sv["rays"].shape[0], sv["rays"].shape[1]
+
+        def g(t, sb):
+            if t is None or t.numel() == 0:
+                return None
+            t = t.detach().to(dev, torch.float32).contiguous()
+            return t[sb].contiguous()
+
+        keep = []
+        for sb in range(SB):
+            s_ = _lib.RenderSaved(z_coarse=sv["z_coarse"][sb].data_ptr(), sample_coarse=sv["sample_coarse"][sb].data_ptr())
+            if ctx.has_fine:
+                s_.z_fine = sv["z_fine"][sb].data_ptr()
+                s_.sample_fine = sv["sample_fine"][sb].data_ptr()
+            parts = [g(x, sb) for x in (g_rgb_c, g_depth_c, g_w_c, g_rgb_f, g_depth_f, g_w_f)]
+            keep.append(parts)
+            gr = _lib.RenderGrads(*[None if p is None else p.data_ptr() for p in parts])
+            check(L.pny_render_backward(model._scene(sb), ptr(sv["rays"][sb]), B, C.byref(sv["opts"][sb]), C.byref(s_),
+                                        C.byref(gr), 1, st))
+        return (None, None, None, None, None) + tuple(grads)
+
+
 class NeRFRenderer(torch.nn.Module):
     """Drop-in for reference src/render/nerf.py:51 (ctor :68-102, forward :257-309,
     sched_step :324-344, from_conf :346-358, bind_parallel :360-377)."""
@@ -70,15 +116,36 @@ class NeRFRenderer(torch.nn.Module):
         :param rays [origins (3), directions (3), near (1), far (1)] (SB, B, 8)
         :return dict(coarse=dict(rgb (SB,B,3), depth (SB,B)[, weights (SB,B,Kc)]), fine=dict(...))
         ``fine`` is absent when n_fine == 0 (callers test ``len(fine) > 0``, PixelNerfTrainer.py:140-143).
-        """
+
+        Under autograd (grad mode on and MLP parameters that require grad) the call goes through ``_RenderFunction``:
+        same forward kernels, and ``loss.backward()`` fills ``.grad`` of the MLP parameters through
+        pny_render_backward (include/pnyolo.h).  The encoder is not differentiated: it must be frozen
+        (``stop_encoder_grad`` / ``--freeze_enc`` of the reference, train/train.py:70-73)."""
         if self.sched is not None and self.last_sched.item() > 0:
             self.n_coarse = self.sched[1][self.last_sched.item() - 1]
             self.n_fine = self.sched[2][self.last_sched.item() - 1]
         assert len(rays.shape) == 3
         if self.training and self.noise_std > 0.0:
-            raise NotImplementedError("sigma noise (training only) is not part of the forward-only path")
-        if torch.is_grad_enabled() and (rays.requires_grad or model.training):
-            raise RuntimeError("libpnyolo is forward-only (SURVEY.md 8f): render in eval() mode or under no_grad()")
+            raise NotImplementedError("sigma noise (noise_std > 0, training only) is not implemented")
+        params = model.trainable_mlp_parameters() if torch.is_grad_enabled() else []
+        if not params:
+            res, _ = self._render(model, rays, want_weights, save=False)
+            return res
+        model.check_differentiable()
+        kf = int(self.n_fine) if (self.using_fine and self.n_fine > 0) else 0
+        outs = _RenderFunction.apply(self, model, rays, kf > 0, len(params), *[p for _, p in params])
+        res = {"coarse": {"rgb": outs[0], "depth": outs[1]}}
+        if want_weights:
+            res["coarse"]["weights"] = outs[2]
+        if kf > 0:
+            res["fine"] = {"rgb": outs[3], "depth": outs[4]}
+            if want_weights:
+                res["fine"]["weights"] = outs[5]
+        return res
+
+    def _render(self, model, rays, want_weights, save):
+        """One pny_render call per scene.  save=True also returns what the backward needs: the detached device rays,
+        the sample depths and the per-sample MLP outputs of both passes, and the options of every scene's call."""
         model._sync()
         L = _lib.load()
         dev = model._device()
@@ -99,6 +166,17 @@ class NeRFRenderer(torch.nn.Module):
             res["fine"] = {"rgb": torch.empty(SB, B, 3, **f32), "depth": torch.empty(SB, B, **f32)}
             if want_weights:
                 res["fine"]["weights"] = torch.empty(SB, B, kc + kf, **f32)
+        saved = None
+        extra = dict(getattr(self, "_debug_out", None) or {})
+        if save:
+            saved = {"rays": rays, "z_coarse": torch.empty(SB, B, kc, **f32), "sample_coarse": torch.empty(SB, B, kc, 4, **f32),
+                     "opts": []}
+            if use_fine:
+                saved["z_fine"] = torch.empty(SB, B, kc + kf, **f32)
+                saved["sample_fine"] = torch.empty(SB, B, kc + kf, 4, **f32)
+            for k in ("z_coarse", "sample_coarse", "z_fine", "sample_fine"):
+                if k in saved:
+                    saved[k] = extra.pop(k, saved[k])   # a debug capture of the same buffer: share it
         draws, self.draws = self.draws, None
         self._calls += 1
         st = stream_of(dev)
@@ -128,10 +206,15 @@ class NeRFRenderer(torch.nn.Module):
                 out.depth_fine = res["fine"]["depth"][sb].data_ptr()
                 if want_weights:
                     out.weights_fine = res["fine"]["weights"][sb].data_ptr()
-            for name, buf in (getattr(self, "_debug_out", None) or {}).items():
+            for name, buf in extra.items():
                 setattr(out, name, buf[sb].data_ptr())
+            if save:
+                for name in ("z_coarse", "sample_coarse", "z_fine", "sample_fine"):
+                    if name in saved:
+                        setattr(out, name, saved[name][sb].data_ptr())
+                saved["opts"].append(o)
             check(L.pny_render(model._scene(sb), ptr(rays[sb]), B, C.byref(o), C.byref(out), st))
-        return res
+        return res, saved
 
     def sched_step(self, steps=1):
         """Sample-count schedule of the reference (nerf.py:324-344): sched = [iterations, n_coarse, n_fine];

@@ -1,0 +1,263 @@
+"""
+Backward pass (-m gpu, real MI355X, through the C ABI): the gradients of the HIP path against torch.autograd through
+the oracle (oracle/pnyolo_oracle.py is written in torch ops and is pinned to the reference's own gradients by
+tests/test_oracle_golden.py::test_training_gradients), and against the reference's gradient digests
+(tests/golden/nerf_grads.npz, captured by tools/make_golden.py from loss.backward() of the imported reference).
+
+Tolerance: every gradient tensor within 1e-4 x its own max |.| (gradients sum 10^4..10^5 fp32 products).
+"""
+import numpy as np
+import pytest
+import torch
+
+import pnyolo_oracle as orc
+from helpers import DEV, dt, load_mlp, maxabs
+from pixel_nerf_yolo_amd import conf as pconf
+from pixel_nerf_yolo_amd import lib as plib
+from pixel_nerf_yolo_amd import synth
+from pixel_nerf_yolo_amd.model import make_model
+from pixel_nerf_yolo_amd.render import NeRFRenderer
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+def grad_check(name, got, ref, rtol=RTOL):
+    ref = torch.as_tensor(np.asarray(ref), dtype=torch.float32)
+    scale = max(float(ref.abs().max()), 1e-20)
+    err = float((got.detach().cpu().float() - ref).abs().max())
+    assert err <= rtol * scale, "%s: max |err| %.3e vs max |grad| %.3e (ratio %.2e)" % (name, err, scale, err / scale)
+    return err / scale
+
+
+# --------------------------------------------------------------------------- composite
+@pytest.mark.parametrize("K,white", [(16, True), (64, False), (96, True), (192, True)])
+def test_composite_backward_vs_autograd(K, white):
+    rs = np.random.RandomState(K)
+    n = 37
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, 6], rays[:, 7] = 0.8, 1.8
+    z = np.sort(rs.uniform(0.8, 1.8, size=(n, K)).astype(np.float32), axis=1)
+    samp = np.concatenate([rs.uniform(0.05, 0.95, size=(n, K, 3)), np.maximum(rs.normal(1.0, 3.0, size=(n, K, 1)), 0.0)],
+                          axis=2).astype(np.float32)
+    samp[3, :, 3] = 0.0            # an empty ray
+    samp[5, K // 2:, 3] = 80.0     # a ray that saturates (alpha -> 1, A -> 1e-10)
+    g_rgb, g_depth = rs.standard_normal((n, 3)).astype(np.float32), rs.standard_normal(n).astype(np.float32)
+    g_w = rs.standard_normal((n, K)).astype(np.float32)
+    zt = torch.from_numpy(z).requires_grad_()
+    st = torch.from_numpy(samp).requires_grad_()
+    w, rgb, depth = orc.composite(torch.from_numpy(rays), zt, st, white)
+    (rgb * torch.from_numpy(g_rgb)).sum().add((depth * torch.from_numpy(g_depth)).sum()).add((w * torch.from_numpy(g_w)).sum()).backward()
+    L = plib.load()
+    d_samp, d_z = torch.empty(n, K, 4, device=DEV), torch.empty(n, K, device=DEV)
+    r_, z_, s_, a_, b_, c_ = dt(rays), dt(z), dt(samp), dt(g_rgb), dt(g_depth), dt(g_w)
+    plib.check(L.pny_composite_backward(plib.ptr(r_), plib.ptr(z_), plib.ptr(s_), n, K, int(white), plib.ptr(a_), plib.ptr(b_),
+                                        plib.ptr(c_), plib.ptr(d_samp), plib.ptr(d_z), plib.stream_of(torch.device(DEV))))
+    torch.cuda.synchronize()
+    # the reference's relu(sigma) has gradient 0 at sigma == 0 (autograd's convention), as the kernel's mask
+    grad_check("d_sample", d_samp, st.grad, 2e-5)
+    grad_check("d_z", d_z, zt.grad, 2e-5)
+    # only some upstream gradients given
+    plib.check(L.pny_composite_backward(plib.ptr(r_), plib.ptr(z_), plib.ptr(s_), n, K, int(white), plib.ptr(a_), None, None,
+                                        plib.ptr(d_samp), None, plib.stream_of(torch.device(DEV))))
+    st.grad = None
+    w, rgb, depth = orc.composite(torch.from_numpy(rays), zt, st, white)
+    (rgb * torch.from_numpy(g_rgb)).sum().backward()
+    grad_check("d_sample(rgb only)", d_samp, st.grad, 2e-5)
+
+
+# --------------------------------------------------------------------------- unambiguous inputs
+# The gradient is a discontinuous function of the inputs: a relu whose pre-activation is within fp32 rounding of zero
+# (|h| ~ 1e-6 for O(1) activations) is masked differently by two correct implementations, and one such unit on one
+# sample moves a gradient tensor by ~1/n_samples of its scale.  With ~10^4 relu units per query point about 7 % of
+# random points have a unit with |h| < 1e-5.  The comparisons below therefore run on points / rays whose every
+# pre-activation (traced through the oracle, pnyolo_oracle.RELU_TRACE) is at least AMBIG away from zero.
+AMBIG = 1e-5
+
+
+def clean_points(sc, xyz, vd, n):
+    """First n of the candidate points whose relu inputs (both MLPs) all satisfy |h| >= AMBIG."""
+    orc.RELU_TRACE = []
+    with torch.no_grad():
+        orc.query(sc, xyz, vd, coarse=True)
+        if sc.mlp_fine is not None:
+            orc.query(sc, xyz, vd, coarse=False)
+    ok = torch.stack(orc.RELU_TRACE).min(dim=0)[0] >= AMBIG
+    orc.RELU_TRACE = None
+    idx = ok.nonzero().flatten()[:n]
+    assert idx.numel() == n, "not enough unambiguous candidates (%d of %d)" % (int(ok.sum()), len(xyz))
+    return idx.numpy()
+
+
+def clean_rays(sc, rays, kc, kf, kfd, draws, n, **kw):
+    """First n of the candidate rays all of whose samples (coarse and fine pass) are unambiguous."""
+    orc.RELU_TRACE = []
+    with torch.no_grad():
+        orc.render(sc, rays, kc, kf, kfd, draws["u_coarse"], draws["u_fine"], draws["u_fine2"], draws["g_depth"], **kw)
+    N = rays.shape[0]
+    ok = torch.ones(N, dtype=torch.bool)
+    for t in orc.RELU_TRACE:                       # (N*K,) per traced relu; K = kc or kc + kf
+        ok &= t.reshape(N, -1).min(dim=1)[0] >= AMBIG
+    orc.RELU_TRACE = None
+    idx = ok.nonzero().flatten()[:n]
+    assert idx.numel() == n, "not enough unambiguous rays (%d of %d)" % (int(ok.sum()), N)
+    return idx.numpy()
+
+
+# --------------------------------------------------------------------------- MLP (query) backward
+def scene_pair(ns, H, W, L, d_out, n_blocks, combine_layer, seed, yolo=False, lat_hw=None):
+    """The same seeded scene as a HIP net (trainable MLP, frozen encoder) and as oracle state with requires_grad."""
+    c = pconf.yolo() if yolo else pconf.default_mv()
+    m = c.d["model"]
+    if L != 512 and not yolo:
+        m["encoder"]["backbone"] = "custom"
+    m["mlp_coarse"].update({"n_blocks": n_blocks, "combine_layer": combine_layer})
+    if not yolo:
+        m["mlp_fine"].update({"n_blocks": n_blocks, "combine_layer": combine_layer})
+    net = make_model(c["model"], stop_encoder_grad=True)
+    sd_c = synth.mlp_state(seed + 1, d_latent=L, d_out=d_out, n_blocks=n_blocks, combine_layer=combine_layer)
+    net.mlp_coarse.load_state_dict({k: torch.from_numpy(v) for k, v in sd_c.items()})
+    sd_f = None
+    if net.mlp_fine is not None:
+        sd_f = synth.mlp_state(seed + 2, d_latent=L, d_out=d_out, n_blocks=n_blocks, combine_layer=combine_layer)
+        net.mlp_fine.load_state_dict({k: torch.from_numpy(v) for k, v in sd_f.items()})
+    net = net.to(DEV).train()
+    hl, wl = lat_hw or (H // 2, W // 2)
+    lat = synth.latent(seed + 3, ns, L, hl, wl)
+    if yolo:
+        src_c2w, _ = synth.scene_cameras(ns, radius=4.0, phi=-25.0)
+        flipyz = np.diag([1.0, -1.0, -1.0, 1.0]).astype(np.float32)
+        poses = np.stack([np.linalg.inv(p @ flipyz) for p in src_c2w]).astype(np.float32)
+        focal, cc = torch.tensor([[40.0, 44.0]]), torch.tensor([[W * 0.5, H * 0.5 - 2]])
+    else:
+        poses, _ = synth.scene_cameras(ns)
+        focal, cc = torch.tensor(0.9 * W), torch.tensor([[W * 0.5, H * 0.5]])
+    net.encode(torch.zeros(1, ns, 3, H, W), torch.from_numpy(poses)[None], focal, c=cc, latent=torch.from_numpy(lat))
+    mc = {k: torch.from_numpy(v).requires_grad_() for k, v in sd_c.items()}
+    mf = None if sd_f is None else {k: torch.from_numpy(v).requires_grad_() for k, v in sd_f.items()}
+    sc = orc.Scene(mc, mf, lat, poses, focal, cc, W, H, yolo=yolo, n_blocks=n_blocks, combine_layer=combine_layer)
+    sc.mlp_coarse, sc.mlp_fine = mc, mf          # Scene() re-wraps tensors: keep the leaves
+    return net, sc
+
+
+def compare_param_grads(net, sc, which=("mlp_coarse", "mlp_fine"), rtol=RTOL):
+    worst = 0.0
+    for pre in which:
+        mlp, ref = getattr(net, pre), getattr(sc, pre)
+        if mlp is None:
+            continue
+        for k, p in mlp.named_parameters():
+            assert p.grad is not None, pre + "." + k
+            r = ref[k].grad if ref[k].grad is not None else torch.zeros_like(ref[k])
+            worst = max(worst, grad_check(pre + "." + k, p.grad, r, rtol))
+    return worst
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(ns=2, L=512, d_out=4, n_blocks=5, combine_layer=3, n=200),        # the shipped multi-view shape
+    dict(ns=3, L=512, d_out=4, n_blocks=5, combine_layer=3, n=65),         # ragged tile
+    dict(ns=1, L=512, d_out=4, n_blocks=3, combine_layer=1000, n=130),     # conf/default.conf: single view, no combine
+    dict(ns=2, L=512, d_out=4, n_blocks=2, combine_layer=0, n=90),         # mean directly after lin_in
+    dict(ns=3, L=512, d_out=4, n_blocks=4, combine_layer=1, n=90),
+    dict(ns=2, L=1792, d_out=4, n_blocks=5, combine_layer=3, n=70, lat_hw=(8, 8)),   # YOLO-sized conditioning
+])
+def test_query_backward_vs_oracle_autograd(cfg):
+    n = cfg["n"]
+    net, sc = scene_pair(cfg["ns"], 32, 40, cfg["L"], cfg["d_out"], cfg["n_blocks"], cfg["combine_layer"], 500 + n,
+                         lat_hw=cfg.get("lat_hw"))
+    rs = np.random.RandomState(n)
+    xyz = rs.uniform(-0.5, 0.5, size=(2 * n + 40, 3)).astype(np.float32)
+    vd = rs.standard_normal((2 * n + 40, 3)).astype(np.float32)
+    keep = clean_points(sc, xyz, vd, n)
+    xyz, vd = xyz[keep], vd[keep]
+    G = rs.standard_normal((n, cfg["d_out"])).astype(np.float32)
+    for coarse in (True, False):
+        net.zero_grad()
+        out = net(dt(xyz)[None], coarse=coarse, viewdirs=dt(vd)[None])
+        assert out.requires_grad
+        (out[0] * dt(G)).sum().backward()
+        for m_ in (sc.mlp_coarse, sc.mlp_fine):
+            for v in m_.values():
+                v.grad = None
+        ref = orc.query(sc, xyz, vd, coarse=coarse)
+        assert maxabs(out[0], ref.detach()) < 1e-4
+        (ref * torch.from_numpy(G)).sum().backward()
+        compare_param_grads(net, sc, which=("mlp_coarse",) if coarse else ("mlp_fine",))
+        other = net.mlp_fine if coarse else net.mlp_coarse
+        assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for p in other.parameters())
+
+
+def test_query_backward_yolo_mode():
+    """d_out = 21 raw outputs (no head non-linearity), L = 1792, latent culling of points behind the camera."""
+    n = 150
+    net, sc = scene_pair(2, 64, 64, 1792, 21, 5, 3, 900, yolo=True, lat_hw=(8, 8))
+    rs = np.random.RandomState(4)
+    xyz = rs.uniform(-3.0, 3.0, size=(2 * n, 3)).astype(np.float32)
+    vd = rs.standard_normal((2 * n, 3)).astype(np.float32)
+    keep = clean_points(sc, xyz, vd, n)
+    xyz, vd = xyz[keep], vd[keep]
+    G = rs.standard_normal((n, 21)).astype(np.float32)
+    out = net(dt(xyz)[None], coarse=True, viewdirs=dt(vd)[None])
+    (out[0] * dt(G)).sum().backward()
+    ref = orc.query(sc, xyz, vd, coarse=True)
+    (ref * torch.from_numpy(G)).sum().backward()
+    compare_param_grads(net, sc, which=("mlp_coarse",))
+
+
+# --------------------------------------------------------------------------- render backward
+def render_loss(out, gt, with_depth=False):
+    loss = torch.nn.functional.mse_loss(out["coarse"]["rgb"], gt) + torch.nn.functional.mse_loss(out["fine"]["rgb"], gt)
+    if with_depth:
+        loss = loss + 0.1 * out["fine"]["depth"].mean() + 0.05 * out["coarse"]["depth"].square().mean()
+    return loss
+
+
+@pytest.mark.parametrize("with_depth", [False, True])
+def test_render_backward_vs_oracle_detached_depth(with_depth):
+    """The trainer's loss (MSE on coarse.rgb + MSE on fine.rgb, PixelNerfTrainer.py:133-156) through the renderer,
+    with the fine pass's depth samples treated as constants on both sides (oracle: detach_fine_depth=True)."""
+    ns, H, W, kc, kf, kfd, n = 2, 32, 32, 16, 8, 4, 40
+    net, sc = scene_pair(ns, H, W, 512, 4, 5, 3, 700)
+    _, tgt = synth.scene_cameras(ns)
+    rs = np.random.RandomState(9)
+    nc = H * W
+    rays = orc.gen_rays(tgt[None], W, H, 0.9 * W, 0.8, 1.8)[0].reshape(-1, 8)
+    dr = dict(u_coarse=rs.rand(nc, kc).astype(np.float32), u_fine=rs.rand(nc, kf - kfd).astype(np.float32),
+              u_fine2=rs.rand(nc, kf - kfd).astype(np.float32), g_depth=rs.randn(nc, kfd).astype(np.float32))
+    keep = clean_rays(sc, rays, kc, kf, kfd, dr, n)
+    rays, dr = rays[torch.from_numpy(keep)], {k: v[keep] for k, v in dr.items()}
+    gt = torch.from_numpy(rs.uniform(0, 1, size=(n, 3)).astype(np.float32))
+    ren = NeRFRenderer(n_coarse=kc, n_fine=kf, n_fine_depth=kfd, white_bkgd=True).train()
+    ren.draws = dr
+    out = ren(net, rays[None].to(DEV), want_weights=True)
+    assert out["fine"]["rgb"].requires_grad
+    hip = {p: {k: v[0] for k, v in out[p].items()} for p in ("coarse", "fine")}
+    render_loss(hip, gt.to(DEV), with_depth).backward()
+    ref = orc.render(sc, rays, kc, kf, kfd, dr["u_coarse"], dr["u_fine"], dr["u_fine2"], dr["g_depth"], detach_fine_depth=True)
+    assert maxabs(out["fine"]["rgb"][0], ref["fine"]["rgb"].detach()) < 1e-4
+    render_loss(ref, gt, with_depth).backward()
+    compare_param_grads(net, sc)
+
+
+def test_training_step_updates_weights():
+    """An optimizer step on the HIP gradients lowers the loss of the same batch (weights re-sync after step())."""
+    ns, H, W, kc, kf, kfd, n = 2, 32, 32, 16, 8, 4, 64
+    net, _ = scene_pair(ns, H, W, 512, 4, 5, 3, 800)
+    _, tgt = synth.scene_cameras(ns)
+    rs = np.random.RandomState(2)
+    rays = orc.gen_rays(tgt[None], W, H, 0.9 * W, 0.8, 1.8)[0].reshape(-1, 8)[torch.from_numpy(rs.choice(H * W, n, replace=False))]
+    gt = torch.from_numpy(rs.uniform(0, 1, size=(1, n, 3)).astype(np.float32)).to(DEV)
+    dr = dict(u_coarse=rs.rand(n, kc).astype(np.float32), u_fine=rs.rand(n, kf - kfd).astype(np.float32),
+              u_fine2=rs.rand(n, kf - kfd).astype(np.float32), g_depth=rs.randn(n, kfd).astype(np.float32))
+    ren = NeRFRenderer(n_coarse=kc, n_fine=kf, n_fine_depth=kfd, white_bkgd=True).train()
+    opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=1e-4)
+    losses = []
+    for _ in range(4):
+        ren.draws = dr
+        out = ren(net, rays[None].to(DEV))
+        loss = torch.nn.functional.mse_loss(out["coarse"]["rgb"], gt) + torch.nn.functional.mse_loss(out["fine"]["rgb"], gt)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < losses[0], losses
