@@ -239,8 +239,9 @@ int pny_scene_enable_timing(pny_scene* s, int enable);
  * needs); inside the backward call the MLP chain is evaluated once more in the reference's operation order with every
  * GEMM operand stashed in HBM (bounded by PNYOLO_STASH_GB, default 16: larger batches are processed in chunks), then
  * the dX chain and the weight-gradient GEMMs run over the stash.
- * Not yet differentiated (documented gaps): the sample depths (the reference lets the fine pass's depth
- * samples depend on the coarse depth, nerf.py:156-167), the latent / encoder, the rays. */
+ * The fine pass's depth samples depend on the coarse depth in the reference (nerf.py:156-167: no detach): that path
+ * (gradient w.r.t. sample positions through the positional code, the projection and the bilinear latent lookup) is
+ * included.  Not differentiated: the latent / encoder, the rays, the cameras. */
 
 /* Gradient target of the state_dict entry `name` ("mlp_coarse.blocks.2.fc_1.weight", ...): a device buffer of the
  * parameter's shape (fp32, contiguous) that the backward calls write / add into.  NULL unbinds.  Borrowed until
@@ -265,6 +266,9 @@ typedef struct pny_render_saved {
     const float* sample_coarse; /* (n, n_coarse, 4) */
     const float* z_fine;        /* (n, n_coarse+n_fine) */
     const float* sample_fine;   /* (n, n_coarse+n_fine, 4) */
+    const float* depth_coarse;  /* (n) the forward's coarse depth: the centre of the fine pass's depth samples.  Given, the
+                                   fine loss is also propagated into mlp_coarse through those samples' positions, as the
+                                   reference does (src/render/nerf.py:156-167, 296-298); NULL treats them as constants. */
 } pny_render_saved;
 /* Upstream gradients w.r.t. the outputs of pny_render; any may be NULL (= zero). */
 typedef struct pny_render_grads {

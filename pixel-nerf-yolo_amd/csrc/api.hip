@@ -161,6 +161,7 @@ static int pack_mlp(pny_model* m, const std::string& pre, MlpWeights& w, MlpWeig
         return 0;
     };
     if (d.d_out > D_IN_PAD) return fail(PNY_ERR_ARG, "d_out > 64");
+    if ((rc = plain(pre + "lin_in.weight", {HID, d_in}, &wt.w_in_plain))) return rc;
     if ((rc = packedT(pre + "lin_out.weight", d.d_out, HID, &wt.wT_out))) return rc;
     for (int b = 0; b < d.n_blocks; ++b) {
         const std::string p = pre + "blocks." + std::to_string(b);
@@ -298,7 +299,8 @@ void pny_scene_destroy(pny_scene* s) {
     s->enc_work.release();
     s->zp[0].release();
     s->zp[1].release();
-    for (DevBuf* b : {&s->x_stash, &s->dy_stash, &s->dw_partial, &s->dw_bias, &s->dw_tables, &s->d_samp, &s->out_tmp, &s->dz_tmp})
+    for (DevBuf* b : {&s->x_stash, &s->dy_stash, &s->dw_partial, &s->dw_bias, &s->dw_tables, &s->d_samp, &s->out_tmp, &s->dz_tmp,
+                      &s->sel_tmp, &s->gdepth_tmp})
         b->release();
     for (auto e : s->ev) (void)hipEventDestroy(e);
     if (s->order_ev) (void)hipEventDestroy(s->order_ev);
@@ -515,11 +517,13 @@ static double mlp_flops_per_point(const pny_model_desc& d, int ns, bool with_lin
 // once per (scene latent, weights) on the caller's stream and cached.  AUTO uses it when the launch has
 // at least twice as many points as the latent has pixels per view (the projection costs one lin_z per
 // PIXEL instead of one per (sample, view); tiny training-size batches on large maps stay direct).
-static int ensure_projection(pny_scene* s, int which, long long n_points, hipStream_t st, const float** zp) {
+namespace pny {
+int ensure_projection(pny_scene* s, int which, long long n_points, hipStream_t st, const float** zp, bool force) {
     *zp = nullptr;
     const pny_model* m = s->m;
-    if (!m->has_zproj || s->zp_mode == PNY_PROJECTION_OFF) return 0;
-    if (s->zp_mode == PNY_PROJECTION_AUTO && n_points < 2ll * s->hl * s->wl) return 0;
+    if (!m->has_zproj) return 0;
+    if (!force && s->zp_mode == PNY_PROJECTION_OFF) return 0;
+    if (!force && s->zp_mode == PNY_PROJECTION_AUTO && n_points < 2ll * s->hl * s->wl) return 0;
     const int nvb = view_blocks(m->desc);
     if ((long long)s->hl * s->wl * nvb * HID >= (1ll << 31)) return 0;  // 32-bit tap offsets: stay direct
     if (s->zp_generation != m->generation) {
@@ -538,6 +542,7 @@ static int ensure_projection(pny_scene* s, int which, long long n_points, hipStr
     *zp = s->zp[which].f();
     return 0;
 }
+}  // namespace pny
 
 namespace pny {
 int fill_mlp_args(pny_scene* s, int mode, const float* xyz, const float* dirs, const float* rays, const float* z, int K,

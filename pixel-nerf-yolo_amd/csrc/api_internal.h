@@ -40,6 +40,7 @@ int fail(int code, const std::string& msg);
 
 // transposed packed weights of one MLP (A operands of the backward chain, mlp_bwd.hip)
 struct MlpWeightsT {
+    const float* w_in_plain;  // lin_in.weight as stored (512, d_in): input gradients (mlp_bwd.hip mlp_dz_kernel)
     const float* wT_out;
     const float* wT_fc0[MAX_BLOCKS];
     const float* wT_fc1[MAX_BLOCKS];
@@ -90,7 +91,7 @@ struct pny_scene {
     int last_launches = 0;
     // stream the last call on this scene was enqueued on (see enter_stream)
     // training workspace (train_api.hip)
-    DevBuf x_stash, dy_stash, dw_partial, dw_bias, dw_tables, d_samp, out_tmp, dz_tmp;
+    DevBuf x_stash, dy_stash, dw_partial, dw_bias, dw_tables, d_samp, out_tmp, dz_tmp, sel_tmp, gdepth_tmp;
     std::vector<char> table_host;
     hipStream_t last_stream = nullptr;
     bool has_last_stream = false;
@@ -102,6 +103,8 @@ namespace pny {
 int enter_stream(pny_scene* s, hipStream_t st);
 int check_ready(pny_scene* s, const char* who);
 int view_blocks(const pny_model_desc& d);
+// projected latent maps of the coarse (0) / fine (1) MLP, computed if stale; force = regardless of the scene's mode
+int ensure_projection(pny_scene* s, int which, long long n_points, hipStream_t st, const float** zp, bool force = false);
 // MlpArgs of a launch on this scene in the reference's operation order (no projected latent); tiles of 64 samples
 int fill_mlp_args(pny_scene* s, int mode, const float* xyz, const float* dirs, const float* rays, const float* z, int K,
                   long long n_points, int coarse, float* out, MlpArgs* a);

@@ -20,10 +20,17 @@
 #include <vector>
 
 #include "mlp_core.h"
+#include "pny_rng.h"
 
 namespace pny {
 
 // ---------------------------------------------------------------------------------------------- chain kernel
+__device__ __forceinline__ float bwd_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
 __device__ __forceinline__ WStream wstream_raw(const float* base, unsigned bytes, int lane) {
     WStream w;
     w.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
@@ -391,11 +398,6 @@ void launch_dw_reduce(const DwTarget* targets_dev, int n_targets, long long max_
 //   dL/ds_k = dL/dalpha_k delta_k exp(-delta_k s_k);  dL/ddelta_k = dL/dalpha_k s_k exp(-delta_k s_k)
 // Outputs: d_samp (n,K,4) = gradient w.r.t. the model's per-sample outputs [rgb (after sigmoid), sigma (after relu)];
 // d_z (n,K) (optional) = gradient w.r.t. the sample depths through delta and through depth = sum w z.
-__device__ __forceinline__ float bwd_wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
 
 __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restrict__ rays, const float* __restrict__ z,
                                                             const float* __restrict__ samp, const float* __restrict__ noise,
@@ -496,6 +498,188 @@ void launch_composite_bwd(const float* rays, const float* z, const float* samp, 
     if (n == 0) return;
     hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), (size_t)4 * 2 * k * sizeof(float), st,
                        rays, z, samp, noise, n, k, white, g_rgb, g_depth, g_w, d_samp, d_z);
+}
+
+// ---------------------------------------------------------------------------------------------- sample-depth gradients
+// The reference centres the fine pass's depth samples on the coarse pass's depth WITHOUT detaching it
+// (nerf.py:156-167, 296-298): the fine loss reaches the coarse MLP through the positions of those samples.
+//   dL/dz_j = [composite: through the deltas and the depth sum]  +  d . dL/dp_j,   p_j = o + z_j d,
+//   dL/dp = sum over views R^T (dL/dxr + dL/dxc):  xr = R p feeds the positional code (code.py:30-42) and, as
+//   xc = xr + t, the projection uv (models.py:219-230) whose bilinear lookup (encoder.py:101) is differentiated as
+//   grid_sampler does (zeros padding: out-of-range taps count as 0).
+// Only the kfd depth samples per ray need it, so this is a separate small kernel over the dY stash of the fine pass
+// (one wavefront per selected sample) and not part of the chain kernel:
+//   dL/d(code input) = lin_in^T dh_in(0);   dL/d(ix, iy) = sum_b dh_in(b) . d interp(ZP_b) / d(ix, iy)
+// with ZP_b the per-scene projected maps lin_z[b](latent) (the lookup is linear in the latent, api.hip
+// ensure_projection), so the lin_z^T GEMMs are not needed.
+
+// sel[ray * kfd + j] = index (ray * kt + position) of depth sample j in the sorted fine depths, or -1 when the sample
+// was clamped to [near, far] (no gradient passes the clamp).  Re-creates the forward's draw (explicit or Philox).
+__global__ void locate_depth_samples_kernel(const float* __restrict__ rays, const float* __restrict__ depth_c,
+                                            const float* __restrict__ g, uint64_t seed, const float* __restrict__ z_fine,
+                                            long long n, int kt, int kfd, float depth_std, int* __restrict__ sel) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * kfd) return;
+    const long long ray = i / kfd;
+    const float near = rays[ray * 8 + 6], far = rays[ray * 8 + 7];
+    const float gg = g ? g[i] : normal_at(seed, STREAM_DEPTH, (uint64_t)i);
+    const float zz = depth_c[ray] + gg * depth_std;
+    const float zc = fmaxf(fminf(zz, far), near);
+    const float* zr = z_fine + ray * kt;
+    int lo = 0, hi = kt;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (zr[mid] < zc)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    const bool inside = zz > near && zz < far;
+    sel[i] = (inside && lo < kt && zr[lo] == zc) ? (int)(ray * kt + lo) : -1;
+}
+
+__global__ __launch_bounds__(256) void mlp_dz_kernel(const DzArgs a) {
+    __shared__ float sh[4][HID];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + wv;
+    if (i >= a.n_sel) return;
+    const int idx = a.sel[i];
+    if (idx < 0) return;
+    const long long loc = (long long)idx - a.p0;
+    const long long tile = loc >> 6;
+    const int m = (int)(loc & 63);
+    const long long ray = idx / a.K;
+    const float4* rr = reinterpret_cast<const float4*>(a.rays + ray * 8);
+    const float4 r0 = rr[0], r1 = rr[1];
+    const float zz = a.z[idx];
+    const float d[3] = {r0.w, r1.x, r1.y};
+    const float p[3] = {r0.x + zz * d[0], r0.y + zz * d[1], r0.z + zz * d[2]};
+    const float* dy_rec = a.dy_stash + tile * a.lay.dy_tile;
+    const int ncode = 3 + 6 * a.num_freqs;
+    float acc = 0.f;
+    for (int v = 0; v < a.NS; ++v) {
+        const Cam cam = a.cams[v];
+        float xr[3], xc[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            xr[k] = cam.w2c[4 * k + 0] * p[0] + cam.w2c[4 * k + 1] * p[1] + cam.w2c[4 * k + 2] * p[2];
+            xc[k] = xr[k] + cam.w2c[4 * k + 3];
+        }
+        // ---- positional code: g_in = lin_in^T dh_in(0), then d sin(phase + x f) / dx = cos(.) f
+        const float* dh0 = a.nvb > 0 ? dy_rec + (size_t)v * a.lay.dy_view + STASH_SLOT
+                                     : dy_rec + a.lay.dy_post + STASH_SMALL + (size_t)(a.npost > 0 ? 2 : 0) * STASH_SLOT;
+        {
+            const float4 h0 = *reinterpret_cast<const float4*>(dh0 + ((size_t)(2 * lane) * 64 + m) * 4);
+            const float4 h1 = *reinterpret_cast<const float4*>(dh0 + ((size_t)(2 * lane + 1) * 64 + m) * 4);
+            *reinterpret_cast<float4*>(&sh[wv][8 * lane]) = h0;
+            *reinterpret_cast<float4*>(&sh[wv][8 * lane + 4]) = h1;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float gin = 0.f;
+        if (lane < a.d_in)
+            for (int n = 0; n < HID; ++n) gin += a.w_in[(size_t)n * a.d_in + lane] * sh[wv][n];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int dim = -1;
+        float c = 0.f;
+        if (lane < 3) {
+            dim = lane;
+            c = gin;
+        } else if (lane < ncode) {
+            const int e = lane - 3;
+            const int fi = e / 6, ph = (e / 3) & 1;
+            dim = e % 3;
+            const float freq = a.freq_factor * (float)(1 << fi);
+            const float arg = (ph ? 1.57079632679489661923f : 0.f) + xr[dim] * freq;
+            c = gin * (cosf(arg) * freq);
+        }
+        float gx[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gx[k] = bwd_wave_sum(dim == k ? c : 0.f);
+        // ---- projection + bilinear lookup of the projected maps
+        if (a.nvb > 0 && a.zp) {
+            const float sgn = a.yolo ? 1.0f : -1.0f;
+            float ux = sgn * xc[0] / xc[2], uy = sgn * xc[1] / xc[2];
+            ux = ux * cam.fx + cam.cx;
+            uy = uy * cam.fy + cam.cy;
+            const float gxn = ux * a.sx - 1.0f, gyn = uy * a.sy - 1.0f;
+            const float ix = ((gxn + 1.0f) / 2.0f) * (float)(a.Wl - 1);
+            const float iy = ((gyn + 1.0f) / 2.0f) * (float)(a.Hl - 1);
+            const float x0 = floorf(ix), y0 = floorf(iy);
+            const float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
+            const float xs[4] = {x0, x1, x0, x1};
+            const float ys[4] = {y0, y0, y1, y1};
+            // d(bilinear weight of tap k)/d ix and /d iy: nw = (x1-ix)(y1-iy), ne = (ix-x0)(y1-iy), sw, se
+            const float wx[4] = {-(y1 - iy), (y1 - iy), -(iy - y0), (iy - y0)};
+            const float wy[4] = {-(x1 - ix), -(ix - x0), (x1 - ix), (ix - x0)};
+            const bool cull = (a.yolo && !(xc[2] < 0.0f)) || !(ix == ix) || !(iy == iy);
+            float six = 0.f, siy = 0.f;
+            if (!cull) {
+                const float* zv = a.zp + (size_t)v * a.Hl * a.Wl * a.zp_stride;
+                for (int b = 0; b < a.nvb; ++b) {
+                    const float* dhb = dy_rec + (size_t)v * a.lay.dy_view + (size_t)(2 * b + 1) * STASH_SLOT;
+                    const float4 h0 = *reinterpret_cast<const float4*>(dhb + ((size_t)(2 * lane) * 64 + m) * 4);
+                    const float4 h1 = *reinterpret_cast<const float4*>(dhb + ((size_t)(2 * lane + 1) * 64 + m) * 4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const bool ok = (xs[k] >= 0.f) && (xs[k] <= (float)(a.Wl - 1)) && (ys[k] >= 0.f) && (ys[k] <= (float)(a.Hl - 1));
+                        if (!ok) continue;
+                        const float* tp = zv + ((size_t)((int)ys[k] * a.Wl + (int)xs[k])) * a.zp_stride + b * HID + 8 * lane;
+                        const float4 t0 = *reinterpret_cast<const float4*>(tp);
+                        const float4 t1 = *reinterpret_cast<const float4*>(tp + 4);
+                        const float dot = h0.x * t0.x + h0.y * t0.y + h0.z * t0.z + h0.w * t0.w + h1.x * t1.x + h1.y * t1.y +
+                                          h1.z * t1.z + h1.w * t1.w;
+                        six += dot * wx[k];
+                        siy += dot * wy[k];
+                    }
+                }
+            }
+            six = bwd_wave_sum(six);
+            siy = bwd_wave_sum(siy);
+            const float dux = six * (a.sx * (float)(a.Wl - 1) * 0.5f), duy = siy * (a.sy * (float)(a.Hl - 1) * 0.5f);
+            const float inv = 1.0f / xc[2];
+            gx[0] += dux * sgn * cam.fx * inv;
+            gx[1] += duy * sgn * cam.fy * inv;
+            gx[2] += -(dux * sgn * cam.fx * xc[0] + duy * sgn * cam.fy * xc[1]) * inv * inv;
+        }
+        // dL/dp = R^T (dL/dxr + dL/dxc);  dL/dz = d . dL/dp
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            acc += d[j] * (cam.w2c[j] * gx[0] + cam.w2c[4 + j] * gx[1] + cam.w2c[8 + j] * gx[2]);
+    }
+    if (lane == 0) a.dz[idx] += acc;
+}
+
+// g_depth_out[ray] = g_depth_in[ray] (or 0) + sum over the ray's unclamped depth samples of dL/dz
+__global__ void depth_grad_gather_kernel(const int* __restrict__ sel, const float* __restrict__ dz, const float* __restrict__ g_in,
+                                         long long n, int kfd, float* __restrict__ g_out) {
+    const long long ray = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ray >= n) return;
+    float s = g_in ? g_in[ray] : 0.f;
+    for (int j = 0; j < kfd; ++j) {
+        const int idx = sel[ray * kfd + j];
+        if (idx >= 0) s += dz[idx];
+    }
+    g_out[ray] = s;
+}
+
+void launch_locate_depth_samples(const float* rays, const float* depth_c, const float* g, uint64_t seed, const float* z_fine,
+                                 long long n, int kt, int kfd, float depth_std, int* sel, hipStream_t st) {
+    const long long tot = n * kfd;
+    if (tot == 0) return;
+    hipLaunchKernelGGL(locate_depth_samples_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, rays, depth_c, g, seed,
+                       z_fine, n, kt, kfd, depth_std, sel);
+}
+void launch_mlp_dz(const DzArgs& a, hipStream_t st) {
+    if (a.n_sel <= 0) return;
+    hipLaunchKernelGGL(mlp_dz_kernel, dim3((unsigned)((a.n_sel + 3) / 4)), dim3(256), 0, st, a);
+}
+void launch_depth_grad_gather(const int* sel, const float* dz, const float* g_in, long long n, int kfd, float* g_out, hipStream_t st) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(depth_grad_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sel, dz, g_in, n, kfd, g_out);
 }
 
 }  // namespace pny

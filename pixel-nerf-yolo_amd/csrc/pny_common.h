@@ -131,6 +131,29 @@ struct DwTarget {
     int splits;
     long long part_off, bias_off;
 };
+// Gradient w.r.t. the depths of selected samples through the MLP inputs (mlp_bwd.hip mlp_dz_kernel).
+struct DzArgs {
+    const float* dy_stash;
+    StashLayout lay;
+    const int* sel;       // n_sel global sample indices (ray * K + position) inside this chunk, or -1
+    int n_sel;
+    long long p0;         // global index of the chunk's first sample
+    const float* rays;    // full arrays of the pass
+    const float* z;
+    int K;
+    const float* w_in;    // lin_in.weight (512, d_in) row-major
+    int d_in;
+    const float* zp;      // projected maps of this MLP (api.hip ensure_projection) or null
+    int zp_stride;
+    int NS, Hl, Wl, nvb, npost, yolo, num_freqs;
+    float freq_factor, sx, sy;
+    float* dz;            // (n_points of the pass) accumulated
+    Cam cams[MAX_VIEWS];
+};
+void launch_locate_depth_samples(const float* rays, const float* depth_c, const float* g, uint64_t seed, const float* z_fine,
+                                 long long n, int kt, int kfd, float depth_std, int* sel, hipStream_t st);
+void launch_mlp_dz(const DzArgs& a, hipStream_t st);
+void launch_depth_grad_gather(const int* sel, const float* dz, const float* g_in, long long n, int kfd, float* g_out, hipStream_t st);
 void launch_mlp_bwd(const BwdArgs& a, int grid, hipStream_t st);
 void launch_dw_gemm(const DwJob* jobs_dev, const DwItem* items_dev, int n_items, const float* x_stash, const float* dy_stash,
                     long long x_tile, long long dy_tile, float* partial, float* bias_partial, hipStream_t st);

@@ -151,8 +151,11 @@ size_t stash_budget_bytes() {
 
 // Backward of one MLP evaluation over n_points query points (mode 0: xyz / dirs; mode 1: rays + z with K samples per
 // ray): d_out (n_points, d_out) -> bound parameter gradients.  Points are processed in chunks that fit the stash.
+// dz_sel / dz_out (mode 1 only, optional): per ray kfd sample indices (ray * K + position, or -1) whose depth gradient
+// through the MLP inputs is added to dz_out (n_points).
 int mlp_backward(pny_scene* s, int mode, const float* xyz, const float* dirs, const float* rays, const float* z, int K,
-                 long long n_points, int coarse, const float* d_out, int accumulate, hipStream_t st) {
+                 long long n_points, int coarse, const float* d_out, int accumulate, hipStream_t st,
+                 const int* dz_sel = nullptr, int kfd = 0, float* dz_out = nullptr) {
     if (n_points == 0) return 0;
     pny_model* m = s->m;
     const pny_model_desc& d = m->desc;
@@ -173,6 +176,11 @@ int mlp_backward(pny_scene* s, int mode, const float* xyz, const float* dirs, co
     if ((rc = s->dy_stash.reserve((size_t)chunk_tiles_max * plan.lay.dy_tile * sizeof(float)))) return rc;
     if ((rc = s->out_tmp.reserve((size_t)chunk_pts * d.d_out * sizeof(float)))) return rc;
     std::vector<DwItem> items;
+    const float* zp_maps = nullptr;
+    if (dz_sel && view_blocks(d) > 0) {
+        if ((rc = ensure_projection(s, fine_w ? 1 : 0, 0, st, &zp_maps, true))) return rc;
+        if (!zp_maps) return fail(PNY_ERR_ARG, "sample-depth gradients need the projected latent maps (latent too large)");
+    }
     for (long long p0 = 0; p0 < n_points; p0 += chunk_pts) {
         const long long np = std::min(chunk_pts, n_points - p0);
         const int n_tiles = (int)((np + 63) / 64);
@@ -212,6 +220,37 @@ int mlp_backward(pny_scene* s, int mode, const float* xyz, const float* dirs, co
         b.yolo = d.yolo;
         launch_mlp_bwd(b, grid, st);
         PNY_HIP(hipGetLastError());
+        // 2b. gradient w.r.t. the depths of the selected samples through the MLP inputs (fine pass of a render)
+        if (dz_sel && mode == 1) {
+            DzArgs dz;
+            memset(&dz, 0, sizeof(dz));
+            dz.dy_stash = s->dy_stash.f();
+            dz.lay = plan.lay;
+            dz.sel = dz_sel + (p0 / K) * kfd;
+            dz.n_sel = (int)((np / K) * kfd);
+            dz.p0 = p0;
+            dz.rays = rays;
+            dz.z = z;
+            dz.K = K;
+            dz.w_in = wt.w_in_plain;
+            dz.d_in = 3 + 6 * d.num_freqs + 3;
+            dz.zp = zp_maps;
+            dz.zp_stride = view_blocks(d) * HID;
+            dz.NS = s->ns;
+            dz.Hl = s->hl;
+            dz.Wl = s->wl;
+            dz.nvb = view_blocks(d);
+            dz.npost = d.n_blocks - view_blocks(d);
+            dz.yolo = d.yolo;
+            dz.num_freqs = d.num_freqs;
+            dz.freq_factor = d.freq_factor;
+            dz.sx = a.sx;
+            dz.sy = a.sy;
+            dz.dz = dz_out;
+            memcpy(dz.cams, s->cams, sizeof(Cam) * (size_t)s->ns);
+            launch_mlp_dz(dz, st);
+            PNY_HIP(hipGetLastError());
+        }
         // 3. weight-gradient GEMMs over the two stashes + deterministic split reduction into the bound gradients
         long long part_floats = 0, bias_floats = 0;
         build_items(plan, n_tiles, cus, items, &part_floats, &bias_floats);
@@ -296,16 +335,38 @@ int pny_render_backward(pny_scene* s, const float* rays_dev, int64_t n, const pn
     bool first = true;
     const bool any_f = o->n_fine > 0 && (g->rgb_fine || g->depth_fine || g->weights_fine);
     const bool any_c = g->rgb_coarse || g->depth_coarse || g->weights_coarse;
+    // The fine pass's depth samples are centred on the (attached) coarse depth (nerf.py:156-167, 296-298): the fine
+    // loss reaches mlp_coarse through those samples' positions.  dL/dz of the fine samples = composite part + MLP-input
+    // part; summed over a ray's unclamped depth samples it is an extra dL/d(depth_coarse).
+    const int kfd = o->n_fine_depth;
+    const bool depth_path = any_f && kfd > 0 && sv->depth_coarse;
+    const float* g_depth_c = g->depth_coarse;
     if (any_f) {
+        float* dz = nullptr;
+        int* sel = nullptr;
+        if (depth_path) {
+            if ((rc = s->dz_tmp.reserve((size_t)n * kt * sizeof(float)))) return rc;
+            if ((rc = s->sel_tmp.reserve((size_t)n * kfd * sizeof(int)))) return rc;
+            if ((rc = s->gdepth_tmp.reserve((size_t)n * sizeof(float)))) return rc;
+            dz = s->dz_tmp.f();
+            sel = reinterpret_cast<int*>(s->sel_tmp.p);
+            launch_locate_depth_samples(rays_dev, sv->depth_coarse, o->g_depth_dev, o->seed, sv->z_fine, n, kt, kfd, o->depth_std, sel, st);
+        }
         launch_composite_bwd(rays_dev, sv->z_fine, sv->sample_fine, nullptr, n, kt, o->white_bkgd, g->rgb_fine, g->depth_fine,
-                             g->weights_fine, s->d_samp.f(), nullptr, st);
+                             g->weights_fine, s->d_samp.f(), dz, st);
         PNY_HIP(hipGetLastError());
-        if ((rc = mlp_backward(s, 1, nullptr, nullptr, rays_dev, sv->z_fine, kt, (long long)n * kt, 0, s->d_samp.f(), accumulate, st)))
+        if ((rc = mlp_backward(s, 1, nullptr, nullptr, rays_dev, sv->z_fine, kt, (long long)n * kt, 0, s->d_samp.f(), accumulate, st,
+                               sel, kfd, dz)))
             return rc;
+        if (depth_path) {
+            launch_depth_grad_gather(sel, dz, g->depth_coarse, n, kfd, s->gdepth_tmp.f(), st);
+            PNY_HIP(hipGetLastError());
+            g_depth_c = s->gdepth_tmp.f();
+        }
         first = false;
     }
-    if (any_c) {
-        launch_composite_bwd(rays_dev, sv->z_coarse, sv->sample_coarse, nullptr, n, kc, o->white_bkgd, g->rgb_coarse, g->depth_coarse,
+    if (any_c || depth_path) {
+        launch_composite_bwd(rays_dev, sv->z_coarse, sv->sample_coarse, nullptr, n, kc, o->white_bkgd, g->rgb_coarse, g_depth_c,
                              g->weights_coarse, s->d_samp.f(), nullptr, st);
         PNY_HIP(hipGetLastError());
         if ((rc = mlp_backward(s, 1, nullptr, nullptr, rays_dev, sv->z_coarse, kc, (long long)n * kc, 1, s->d_samp.f(),

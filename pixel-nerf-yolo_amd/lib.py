@@ -42,7 +42,7 @@ class RenderOut(C.Structure):
 
 
 class RenderSaved(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("z_coarse", "sample_coarse", "z_fine", "sample_fine")]
+    _fields_ = [(n, C.c_void_p) for n in ("z_coarse", "sample_coarse", "z_fine", "sample_fine", "depth_coarse")]
 
 
 class RenderGrads(C.Structure):

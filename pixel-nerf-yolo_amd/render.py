@@ -48,6 +48,7 @@ class _RenderFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, renderer, model, rays, has_fine, n_params, *params):
         res, saved = renderer._render(model, rays, want_weights=True, save=True)
+        saved["depth_coarse"] = res["coarse"]["depth"]
         ctx.renderer, ctx.model, ctx.saved, ctx.has_fine = renderer, model, saved, has_fine
         ctx.white_bkgd = bool(renderer.white_bkgd)
         ctx.set_materialize_grads(False)
@@ -76,6 +77,8 @@ class _RenderFunction(torch.autograd.Function):
         keep = []
         for sb in range(SB):
             s_ = _lib.RenderSaved(z_coarse=sv["z_coarse"][sb].data_ptr(), sample_coarse=sv["sample_coarse"][sb].data_ptr())
+            if not getattr(ctx.renderer, "_detach_fine_depth", False):   # test aid: treat the depth samples as constants
+                s_.depth_coarse = sv["depth_coarse"][sb].data_ptr()
             if ctx.has_fine:
                 s_.z_fine = sv["z_fine"][sb].data_ptr()
                 s_.sample_fine = sv["sample_fine"][sb].data_ptr()
@@ -213,6 +216,7 @@ class NeRFRenderer(torch.nn.Module):
                     if name in saved:
                         setattr(out, name, saved[name][sb].data_ptr())
                 saved["opts"].append(o)
+                saved["keep"] = keep   # the explicit draws are read again by the backward (depth samples)
             check(L.pny_render(model._scene(sb), ptr(rays[sb]), B, C.byref(o), C.byref(out), st))
         return res, saved
 

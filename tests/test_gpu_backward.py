@@ -212,29 +212,36 @@ def render_loss(out, gt, with_depth=False):
     return loss
 
 
-@pytest.mark.parametrize("with_depth", [False, True])
-def test_render_backward_vs_oracle_detached_depth(with_depth):
-    """The trainer's loss (MSE on coarse.rgb + MSE on fine.rgb, PixelNerfTrainer.py:133-156) through the renderer,
-    with the fine pass's depth samples treated as constants on both sides (oracle: detach_fine_depth=True)."""
+@pytest.mark.parametrize("with_depth,detach", [(False, True), (True, True), (False, False), (True, False)])
+def test_render_backward_vs_oracle(with_depth, detach):
+    """The trainer's loss (MSE on coarse.rgb + MSE on fine.rgb, PixelNerfTrainer.py:133-156) through the renderer.
+    detach = False is the reference's graph: the fine pass's depth samples are centred on the ATTACHED coarse depth
+    (nerf.py:156-167, 296-298), so the fine loss reaches mlp_coarse through the sample positions (positional code,
+    projection, bilinear latent lookup).  detach = True cuts that path on both sides (isolates the parameter path)."""
     ns, H, W, kc, kf, kfd, n = 2, 32, 32, 16, 8, 4, 40
     net, sc = scene_pair(ns, H, W, 512, 4, 5, 3, 700)
     _, tgt = synth.scene_cameras(ns)
     rs = np.random.RandomState(9)
     nc = H * W
-    rays = orc.gen_rays(tgt[None], W, H, 0.9 * W, 0.8, 1.8)[0].reshape(-1, 8)
+    # near = 0.3: with random weights the coarse depth (sum of w z with sum w < 1) falls below 0.8, and depth samples
+    # clamped to `near` carry no gradient -- the path under test needs them inside (near, far)
+    rays = orc.gen_rays(tgt[None], W, H, 0.9 * W, 0.3, 1.8)[0].reshape(-1, 8)
     dr = dict(u_coarse=rs.rand(nc, kc).astype(np.float32), u_fine=rs.rand(nc, kf - kfd).astype(np.float32),
               u_fine2=rs.rand(nc, kf - kfd).astype(np.float32), g_depth=rs.randn(nc, kfd).astype(np.float32))
     keep = clean_rays(sc, rays, kc, kf, kfd, dr, n)
     rays, dr = rays[torch.from_numpy(keep)], {k: v[keep] for k, v in dr.items()}
     gt = torch.from_numpy(rs.uniform(0, 1, size=(n, 3)).astype(np.float32))
     ren = NeRFRenderer(n_coarse=kc, n_fine=kf, n_fine_depth=kfd, white_bkgd=True).train()
+    ren._detach_fine_depth = detach
     ren.draws = dr
     out = ren(net, rays[None].to(DEV), want_weights=True)
     assert out["fine"]["rgb"].requires_grad
     hip = {p: {k: v[0] for k, v in out[p].items()} for p in ("coarse", "fine")}
     render_loss(hip, gt.to(DEV), with_depth).backward()
-    ref = orc.render(sc, rays, kc, kf, kfd, dr["u_coarse"], dr["u_fine"], dr["u_fine2"], dr["g_depth"], detach_fine_depth=True)
+    ref = orc.render(sc, rays, kc, kf, kfd, dr["u_coarse"], dr["u_fine"], dr["u_fine2"], dr["g_depth"], detach_fine_depth=detach)
     assert maxabs(out["fine"]["rgb"][0], ref["fine"]["rgb"].detach()) < 1e-4
+    zd = ref["coarse"]["depth"].detach()[:, None] + torch.from_numpy(dr["g_depth"]) * 0.01
+    assert int(((zd > 0.3) & (zd < 1.8)).sum()) > n * kfd // 2        # most depth samples are unclamped
     render_loss(ref, gt, with_depth).backward()
     compare_param_grads(net, sc)
 
@@ -261,3 +268,79 @@ def test_training_step_updates_weights():
         opt.step()
         losses.append(float(loss))
     assert losses[-1] < losses[0], losses
+
+
+def test_render_backward_philox_draws_and_per_view_intrinsics():
+    """In-kernel random draws (perf mode): the backward re-creates the forward's depth-sample draws from the seed.
+    Checked by finite differences of the loss along the gradient direction (no oracle: the draws are not inputs)."""
+    ns, H, W, kc, kf, kfd, n = 2, 32, 32, 16, 8, 4, 48
+    net, _ = scene_pair(ns, H, W, 512, 4, 5, 3, 1100)
+    _, tgt = synth.scene_cameras(ns)
+    rs = np.random.RandomState(3)
+    rays = orc.gen_rays(tgt[None], W, H, 0.9 * W, 0.8, 1.8)[0].reshape(-1, 8)[torch.from_numpy(rs.choice(H * W, n, replace=False))]
+    gt = torch.from_numpy(rs.uniform(0, 1, size=(1, n, 3)).astype(np.float32)).to(DEV)
+    ren = NeRFRenderer(n_coarse=kc, n_fine=kf, n_fine_depth=kfd, white_bkgd=True).train()
+
+    def loss_of():
+        ren.base_seed, ren._calls = 77, 0        # the same Philox streams on every call
+        out = ren(net, rays[None].to(DEV))
+        return torch.nn.functional.mse_loss(out["coarse"]["rgb"], gt) + torch.nn.functional.mse_loss(out["fine"]["rgb"], gt)
+
+    loss = loss_of()
+    net.zero_grad()
+    loss.backward()
+    params = [p for p in net.mlp_coarse.parameters()]
+    gnorm2 = sum(float((p.grad.double() ** 2).sum()) for p in params)
+    assert gnorm2 > 0
+    # directional derivative along the gradient of mlp_coarse: (L(w + eps g) - L(w - eps g)) / (2 eps) ~ |g|^2
+    eps = 2e-3 / gnorm2 ** 0.5
+    with torch.no_grad():
+        for p in params:
+            p.add_(eps * p.grad)
+        lp = float(loss_of())
+        for p in params:
+            p.sub_(2 * eps * p.grad)
+        lm = float(loss_of())
+        for p in params:
+            p.add_(eps * p.grad)
+    fd = (lp - lm) / (2 * eps)
+    assert abs(fd - gnorm2) < 0.05 * gnorm2, (fd, gnorm2)
+
+
+def test_training_gradients_reference_golden(golden):
+    """tests/golden/nerf_grads.npz: the REFERENCE's own gradients (loss.backward() of the imported reference on a
+    2-view, 16 + 8 (4) render of 24 rays, tools/make_golden.py fixture_grads) as digests per tensor: all 60 MLP
+    parameter tensors, 192 seeded entries + sum |.| each, within 1e-4 of the tensor's max (observed 2e-6).  4 of the 24
+    rays have unclamped depth samples, i.e. the fine loss reaches mlp_coarse through the sample positions."""
+    g = golden("nerf_grads")
+    seed, ns, H, W = int(g["seed"]), int(g["NS"]), int(g["H"]), int(g["W"])
+    kc, kf, kfd = int(g["Kc"]), int(g["Kf"]), int(g["Kfd"])
+    net = make_model(pconf.default_mv()["model"], stop_encoder_grad=True)
+    load_mlp(net.mlp_coarse, seed * 10 + 1, 512, 4)
+    load_mlp(net.mlp_fine, seed * 10 + 2, 512, 4)
+    net = net.to(DEV).train()
+    lat = torch.from_numpy(synth.latent(seed * 10 + 3, ns, 512, H // 2, W // 2))
+    net.encode(torch.zeros(1, ns, 3, H, W), torch.from_numpy(g["poses"])[None], torch.tensor(float(g["focal"])),
+               c=torch.from_numpy(g["c"]), latent=lat)
+    ren = NeRFRenderer(n_coarse=kc, n_fine=kf, n_fine_depth=kfd, depth_std=0.01, white_bkgd=True).train()
+    ren.draws = dict(u_coarse=g["draw0_rand_like"], u_fine=g["draw1_rand"], u_fine2=g["draw2_rand_like"], g_depth=g["draw3_randn_like"])
+    out = ren(net, dt(g["rays"])[None], want_weights=True)
+    assert maxabs(out["coarse"]["rgb"][0], g["coarse_rgb"]) < 1e-4 and maxabs(out["fine"]["rgb"][0], g["fine_rgb"]) < 1e-4
+    gt = dt(g["gt"])[None]
+    loss = torch.nn.functional.mse_loss(out["coarse"]["rgb"], gt) + torch.nn.functional.mse_loss(out["fine"]["rgb"], gt)
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    loss.backward()
+    worst, meds = 0.0, []
+    for pre, mlp in (("mlp_coarse.", net.mlp_coarse), ("mlp_fine.", net.mlp_fine)):
+        for k, p in mlp.named_parameters():
+            name = pre + k
+            stat, idx, val = g["g:%s:stat" % name], g["g:%s:idx" % name], g["g:%s:val" % name]
+            f = p.grad.detach().cpu().reshape(-1).double()
+            scale = max(float(stat[2]), 1e-12)
+            err = (f[torch.from_numpy(idx)] - torch.from_numpy(val)).abs() / scale
+            worst = max(worst, float(err.max()))
+            meds.append(float(err.median()))
+            assert float(err.max()) < 1e-4, (name, float(err.max()))
+            assert abs(float(f.abs().sum()) - float(stat[1])) < 1e-4 * float(stat[1]) + 1e-12, name
+    assert max(meds) < 1e-5, max(meds)
+    print("reference gradient digests: worst sampled entry %.2e of max, worst median %.2e" % (worst, max(meds)))
