@@ -82,6 +82,13 @@ int pny_model_load_weights(pny_model* m, const char* name, const float* data_hos
  * PNY_ERR_STATE and names the first missing MLP tensor.  Synchronous.  May be called again after
  * further pny_model_load_weights calls (weights changed); scenes of the model stay valid. */
 int pny_model_finalize(pny_model* m);
+/* Training: device-side weight refresh.  pny_model_bind_param tells the library where a state_dict tensor of the MLPs
+ * lives on the device (fp32, contiguous, its state_dict shape; borrowed until rebound); after the parameters changed
+ * in place (optimizer.step()), pny_model_refresh re-creates every packed operand of both MLPs from those tensors with
+ * one kernel launch on `stream` (no host round trip, asynchronous; ordered behind the scenes' earlier calls).
+ * pny_model_finalize must have run once (it fixes the layout); encoder weights are not refreshed (frozen encoder). */
+int pny_model_bind_param(pny_model* m, const char* name, const float* param_dev);
+int pny_model_refresh(pny_model* m, pny_stream stream);
 /* `net.mlp_fine = None` (reference eval/eval.py:140): with enable=0 the fine pass of pny_render and
  * pny_query(coarse=0) evaluate mlp_coarse.  Default 1 (ignored when the model has no fine MLP). */
 int pny_model_use_fine(pny_model* m, int enable);

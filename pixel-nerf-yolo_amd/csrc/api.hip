@@ -1,6 +1,7 @@
 // C ABI of libpnyolo.so (include/pnyolo.h): handles, weight packing, per-scene state and the
 // launch sequences of a query / render call.  Host-side C++; all arithmetic of the hot path is
 // in the kernels (mlp.hip, render_kernels.hip, encoder.hip).
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -109,11 +110,14 @@ static int pack_mlp(pny_model* m, const std::string& pre, MlpWeights& w, MlpWeig
         const size_t off = plan.blob.size();
         pack_layer(t->data.data(), HID, k_in, k_pad, plan.blob);
         plan.fix.push_back({slot, off});
+        m->repack.push_back({PACK_A, name, "", off, nullptr, HID, k_in, k_pad, 0});
         return 0;
     };
     auto plain = [&](const std::string& name, std::vector<int64_t> shape, const float** slot) -> int {
         if ((rc = need(m, name, shape, &t))) return rc;
-        plan.fix.push_back({slot, plan.add_plain(t->data)});
+        const size_t off = plan.add_plain(t->data);
+        plan.fix.push_back({slot, off});
+        m->repack.push_back({PACK_COPY, name, "", off, nullptr, 0, 0, 0, (int)t->data.size()});
         return 0;
     };
     // `x = x + lin_z[b](z)` (resnetfc.py:176-182) happens right after lin_in (b = 0) or right after
@@ -127,7 +131,9 @@ static int pack_mlp(pny_model* m, const std::string& pre, MlpWeights& w, MlpWeig
             if ((rc = need(m, extra, {HID}, &t2))) return rc;
             for (int i = 0; i < HID; ++i) sum[i] += t2->data[i];
         }
-        plan.fix.push_back({slot, plan.add_plain(sum)});
+        const size_t off = plan.add_plain(sum);
+        plan.fix.push_back({slot, off});
+        m->repack.push_back({extra.empty() ? PACK_COPY : PACK_ADD2, name, extra, off, nullptr, 0, 0, 0, HID});
         return 0;
     };
     auto zbias = [&](int b) { return b < nvb ? pre + "lin_z." + std::to_string(b) + ".bias" : std::string(); };
@@ -158,6 +164,7 @@ static int pack_mlp(pny_model* m, const std::string& pre, MlpWeights& w, MlpWeig
         // W^T is (k_in x n_out): its rows (the GEMM's outputs) must be 512; its K (= n_out) is padded to a ring multiple
         pack_layer(wtr.data(), k_in, n_out, n_out == HID ? HID : D_IN_PAD, plan.blob);
         plan.fix.push_back({slot, off});
+        m->repack.push_back({PACK_AT, name, "", off, nullptr, n_out, k_in, n_out == HID ? HID : D_IN_PAD, 0});
         return 0;
     };
     if (d.d_out > D_IN_PAD) return fail(PNY_ERR_ARG, "d_out > 64");
@@ -199,6 +206,7 @@ int pny_model_create(pny_model** out, const pny_model_desc* desc) {
 void pny_model_destroy(pny_model* m) {
     if (!m) return;
     m->packed.release();
+    m->repack_jobs.release();
     m->enc.release();
     for (float* p : m->zproj_allocs) (void)hipFree(p);
     delete m;
@@ -224,6 +232,8 @@ int pny_model_finalize(pny_model* m) {
     PNY_HIP(hipSetDevice(m->desc.device));
     PackPlan plan;
     int rc;
+    m->repack.clear();
+    m->repack_ready = false;
     PNY_HIP(hipDeviceSynchronize());  // a re-finalize must not overwrite weights a running kernel reads
     if ((rc = pack_mlp(m, "mlp_coarse.", m->coarse, m->coarse_t, plan))) return rc;
     if (m->desc.has_fine && (rc = pack_mlp(m, "mlp_fine.", m->fine, m->fine_t, plan))) return rc;
@@ -250,6 +260,10 @@ int pny_model_finalize(pny_model* m) {
                 std::string err;
                 if (!build_pixel_linear(mats.data(), nvb, HID, m->desc.d_latent, &m->zproj[f], &m->zproj_allocs, &err))
                     return fail(PNY_ERR_HIP, "latent projection weights: " + err);
+                for (int b = 0; b < nvb; ++b)   // stacked along the output rows: block b owns n-tiles [16 b, 16 b + 16)
+                    m->repack.push_back({PACK_NT, pre + "lin_z." + std::to_string(b) + ".weight", "", 0,
+                                         m->zproj[f].w + (size_t)b * 16 * (m->desc.d_latent / 8) * 64 * 4, HID, m->desc.d_latent,
+                                         m->desc.d_latent, 0});
             }
             if (!m->desc.has_fine) m->zproj[1] = m->zproj[0];
             m->has_zproj = true;
@@ -273,6 +287,79 @@ int pny_model_finalize(pny_model* m) {
     return PNY_OK;
 }
 
+int pny_model_bind_param(pny_model* m, const char* name, const float* param_dev) {
+    if (!m || !name) return fail(PNY_ERR_ARG, "pny_model_bind_param: null argument");
+    if (param_dev)
+        m->params_dev[name] = param_dev;
+    else
+        m->params_dev.erase(name);
+    m->repack_ready = false;
+    return PNY_OK;
+}
+
+int pny_model_refresh(pny_model* m, pny_stream stream) {
+    if (!m) return fail(PNY_ERR_ARG, "pny_model_refresh: null model");
+    if (!m->finalized) return fail(PNY_ERR_STATE, "pny_model_refresh: call pny_model_finalize once first (it lays out the packed weights)");
+    PNY_HIP(hipSetDevice(m->desc.device));
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (!m->repack_ready) {   // resolve names -> bound device pointers, upload the job table (once per binding)
+        std::vector<PackJob> jobs;
+        long long max_elems = 0;
+        for (const RepackEntry& e : m->repack) {
+            auto it = m->params_dev.find(e.name);
+            if (it == m->params_dev.end()) return fail(PNY_ERR_STATE, "pny_model_refresh: no device pointer bound for '" + e.name + "'");
+            PackJob j;
+            memset(&j, 0, sizeof(j));
+            j.kind = e.kind;
+            j.src = it->second;
+            if (!e.name2.empty()) {
+                auto it2 = m->params_dev.find(e.name2);
+                if (it2 == m->params_dev.end()) return fail(PNY_ERR_STATE, "pny_model_refresh: no device pointer bound for '" + e.name2 + "'");
+                j.src2 = it2->second;
+            }
+            j.dst = e.dst_abs ? e.dst_abs : m->packed.f() + e.dst_off;
+            j.n_out = e.n_out;
+            j.k_in = e.k_in;
+            j.k_pad = e.k_pad;
+            if (e.kind == PACK_A || e.kind == PACK_NT)
+                j.count = (e.n_out / 32) * (e.k_pad / 8) * 64;       // float4 elements
+            else if (e.kind == PACK_AT)
+                j.count = (e.k_in / 32) * (e.k_pad / 8) * 64;
+            else
+                j.count = e.count;
+            max_elems = std::max(max_elems, (long long)j.count);
+            jobs.push_back(j);
+        }
+        if ((rc = m->repack_jobs.reserve(jobs.size() * sizeof(PackJob)))) return rc;
+        PNY_HIP(hipMemcpy(m->repack_jobs.p, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice));
+        m->n_repack_jobs = (int)jobs.size();
+        m->repack_max_elems = max_elems;
+        m->repack_ready = true;
+    }
+    // order this stream behind the last call of every scene that may still read the packed weights on another stream
+    for (pny_scene* s : m->scenes) {
+        if (s->has_last_stream && s->last_stream != st) {
+            if (!s->order_ev && hipEventCreateWithFlags(&s->order_ev, hipEventDisableTiming) != hipSuccess) {
+                s->order_ev = nullptr;
+                return hip_fail(hipGetLastError(), "hipEventCreate(refresh order)");
+            }
+            if (hipEventRecord(s->order_ev, s->last_stream) == hipSuccess)
+                PNY_HIP(hipStreamWaitEvent(st, s->order_ev, 0));
+            else
+                (void)hipGetLastError();
+            s->last_stream = st;   // the scene's next call must in turn wait for this refresh
+        } else if (!s->has_last_stream) {
+            s->last_stream = st;
+            s->has_last_stream = true;
+        }
+    }
+    launch_repack(reinterpret_cast<const PackJob*>(m->repack_jobs.p), m->n_repack_jobs, m->repack_max_elems, st);
+    PNY_HIP(hipGetLastError());
+    ++m->generation;   // projected maps of every scene are stale
+    return PNY_OK;
+}
+
 int pny_model_use_fine(pny_model* m, int enable) {
     if (!m) return fail(PNY_ERR_ARG, "pny_model_use_fine: null model");
     m->use_fine = enable != 0;
@@ -283,6 +370,7 @@ int pny_scene_create(pny_scene** out, pny_model* m) {
     if (!out || !m) return fail(PNY_ERR_ARG, "pny_scene_create: null argument");
     pny_scene* s = new pny_scene();
     s->m = m;
+    m->scenes.push_back(s);
     if (const char* e = getenv("PNYOLO_PROJECTION")) {  // process-wide default: off | on | auto
         if (!strcmp(e, "off")) s->zp_mode = PNY_PROJECTION_OFF;
         if (!strcmp(e, "on")) s->zp_mode = PNY_PROJECTION_ON;
@@ -293,6 +381,10 @@ int pny_scene_create(pny_scene** out, pny_model* m) {
 
 void pny_scene_destroy(pny_scene* s) {
     if (!s) return;
+    if (s->m) {
+        auto& v = s->m->scenes;
+        v.erase(std::remove(v.begin(), v.end(), s), v.end());
+    }
     s->latent.release();
     s->work.release();
     s->scratch.release();

@@ -38,6 +38,16 @@ struct DevBuf {
 
 int fail(int code, const std::string& msg);
 
+// One packed sub-buffer of the model and how to rebuild it from the state_dict tensor(s) it came from: recorded by
+// pny_model_finalize, replayed on the device by pny_model_refresh (pack.hip).
+struct RepackEntry {
+    int kind;
+    std::string name, name2;
+    size_t dst_off;      // float offset in the packed blob ...
+    float* dst_abs;      // ... or an absolute device pointer (projection weights)
+    int n_out, k_in, k_pad, count;
+};
+
 // transposed packed weights of one MLP (A operands of the backward chain, mlp_bwd.hip)
 struct MlpWeightsT {
     const float* w_in_plain;  // lin_in.weight as stored (512, d_in): input gradients (mlp_bwd.hip mlp_dz_kernel)
@@ -59,6 +69,13 @@ struct pny_model {
     MlpWeights coarse{}, fine{};
     MlpWeightsT coarse_t{}, fine_t{};        // transposed packs for the backward chain
     std::map<std::string, float*> grads;     // gradient targets by state_dict name (pny_model_bind_grad)
+    std::map<std::string, const float*> params_dev;  // live parameter tensors on the device (pny_model_bind_param)
+    std::vector<RepackEntry> repack;
+    DevBuf repack_jobs;
+    int n_repack_jobs = 0;
+    long long repack_max_elems = 0;
+    bool repack_ready = false;
+    std::vector<struct pny_scene*> scenes;   // scenes created on this model (stream ordering of a refresh)
     EncoderWeights enc;                       // folded conv+bn (encoder.h)
     bool has_encoder = false;
     // lin_z[0..nvb) of the coarse / fine MLP stacked into one (nvb*512 x d_latent) pixel-wise map

@@ -90,6 +90,16 @@ struct MlpArgs {
     Cam cams[MAX_VIEWS];
 };
 
+// ---- device-side weight repack (pack.hip): the packed operand layouts rebuilt from the live parameter tensors
+enum { PACK_A = 0, PACK_AT = 1, PACK_NT = 2, PACK_COPY = 3, PACK_ADD2 = 4 };
+struct PackJob {
+    const float* src;
+    const float* src2;
+    float* dst;
+    int kind, n_out, k_in, k_pad, count;
+};
+void launch_repack(const PackJob* jobs_dev, int n_jobs, long long max_elems, hipStream_t st);
+
 // ---- backward pass (mlp_bwd.hip)
 struct BwdArgs {
     // TRANSPOSED packed weights (A operands of dX^T = W^T dY^T), inside the model's packed blob

@@ -59,6 +59,8 @@ SIGNATURES = {
     "pny_model_load_weights": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, c_i64_p, C.c_int]),
     "pny_model_finalize": (C.c_int, [C.c_void_p]),
     "pny_model_use_fine": (C.c_int, [C.c_void_p, C.c_int]),
+    "pny_model_bind_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p]),
+    "pny_model_refresh": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pny_scene_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p]),
     "pny_scene_destroy": (None, [C.c_void_p]),
     "pny_scene_set_cameras": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,

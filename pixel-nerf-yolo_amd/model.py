@@ -232,6 +232,7 @@ class PixelNeRFNet(nn.Module):
         self._h_has_fine = False
         self._h_scenes = []
         self._synced_key = None
+        self._dev_bound = False
         self._timing = False
         self._projection = None  # None = library default (auto, or env PNYOLO_PROJECTION)
 
@@ -251,6 +252,7 @@ class PixelNeRFNet(nn.Module):
         if self._h_model is not None:
             L.pny_model_destroy(self._h_model)
             self._h_model = None
+        self._dev_bound = False
 
     def __del__(self):
         try:
@@ -293,13 +295,28 @@ class PixelNeRFNet(nn.Module):
             raise RuntimeError("a fine MLP was attached after the native model was created without one")
         if key != self._synced_key:
             h = self._h_model
-            for name, t in self.state_dict().items():
-                if name.endswith("num_batches_tracked"):
-                    continue
-                a = np.ascontiguousarray(t.detach().to("cpu", torch.float32).numpy())
-                shape = (C.c_int64 * max(a.ndim, 1))(*a.shape)
-                check(L.pny_model_load_weights(h, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim))
-            check(L.pny_model_finalize(h))
+            old = self._synced_key
+            # Only MLP tensors changed IN PLACE (same storage, new version: an optimizer step) -> device-side refresh:
+            # one kernel launch re-creates the packed operands from the live parameters (pny_model_refresh).
+            in_place = (old is not None and self._dev_bound and len(old) == len(key) and
+                        all(a[:2] == b[:2] and (a[2] == b[2] or a[0].startswith("mlp_")) for a, b in zip(old, key)))
+            if in_place:
+                check(L.pny_model_refresh(h, stream_of(dev)))
+            else:
+                for name, t in self.state_dict().items():
+                    if name.endswith("num_batches_tracked"):
+                        continue
+                    a = np.ascontiguousarray(t.detach().to("cpu", torch.float32).numpy())
+                    shape = (C.c_int64 * max(a.ndim, 1))(*a.shape)
+                    check(L.pny_model_load_weights(h, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim))
+                check(L.pny_model_finalize(h))
+                self._dev_bound = True
+                for name, t in self.state_dict(keep_vars=True).items():
+                    if name.startswith("mlp_"):
+                        ok = t.dtype == torch.float32 and t.is_contiguous() and t.device == dev
+                        self._dev_bound = self._dev_bound and ok
+                        if ok:
+                            check(L.pny_model_bind_param(h, name.encode(), C.c_void_p(t.data_ptr())))
             self._synced_key = key
         # `net.mlp_fine = None` (reference eval.py:140): fine pass falls back to the coarse MLP
         check(L.pny_model_use_fine(self._h_model, int(self.mlp_fine is not None)))

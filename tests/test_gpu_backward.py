@@ -344,3 +344,50 @@ def test_training_gradients_reference_golden(golden):
             assert abs(float(f.abs().sum()) - float(stat[1])) < 1e-4 * float(stat[1]) + 1e-12, name
     assert max(meds) < 1e-5, max(meds)
     print("reference gradient digests: worst sampled entry %.2e of max, worst median %.2e" % (worst, max(meds)))
+
+
+def test_device_refresh_equals_full_reupload():
+    """After in-place parameter updates (optimizer.step()) the packed weights are rebuilt on the device from the live
+    tensors (pny_model_refresh); the result must equal a full host re-pack (pny_model_finalize) bit for bit: forward
+    outputs of both MLPs (projected and reference order) and a backward pass."""
+    ns, H, W = 2, 32, 32
+    net, _ = scene_pair(ns, H, W, 512, 4, 5, 3, 1300)
+    rs = np.random.RandomState(8)
+    xyz, vd = dt(rs.uniform(-0.5, 0.5, size=(1, 300, 3))), dt(rs.standard_normal((1, 300, 3)))
+    G = dt(rs.standard_normal((300, 4)))
+    with torch.no_grad():
+        net(xyz, coarse=True, viewdirs=vd)                       # first sync: host path + binding
+        for p in net.parameters():
+            if p.requires_grad:
+                p.add_(0.01 * torch.randn_like(p))                # in place: same storage, version bump
+    assert net._dev_bound
+    calls = {"n": 0}
+    L = plib.load()
+    orig = L.pny_model_refresh
+
+    def outputs():
+        res = []
+        for mode in ("off", "on"):
+            net.set_latent_projection(mode)
+            with torch.no_grad():
+                res += [net(xyz, coarse=True, viewdirs=vd).clone(), net(xyz, coarse=False, viewdirs=vd).clone()]
+        net.zero_grad()
+        out = net(xyz, coarse=False, viewdirs=vd)
+        (out[0] * G).sum().backward()
+        res += [p.grad.clone() for p in net.mlp_fine.parameters()]
+        return res
+
+    key_before = net._synced_key
+    a = outputs()                                                 # refresh path
+    assert net._synced_key != key_before
+    net.invalidate_weights()                                      # forces the host path on the next call
+    b = outputs()
+    assert len(a) == len(b) and all(torch.equal(x, y) for x, y in zip(a, b))
+    # data_ptr-preserving writes that PyTorch does not version are invisible to the sync: invalidate_weights() is the
+    # documented way to force a re-upload
+    with torch.no_grad():
+        net.mlp_coarse.lin_out.bias.data.zero_()
+    stale = net(xyz, coarse=True, viewdirs=vd)
+    net.invalidate_weights()
+    fresh = net(xyz, coarse=True, viewdirs=vd)
+    assert not torch.equal(stale, fresh)
