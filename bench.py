@@ -101,6 +101,106 @@ def self_launch(args):
     return subprocess.run(cmd, env=env).returncode
 
 
+def train_main(args):
+    """--mode train: the reference's training step (PixelNerfTrainer.calc_losses + optimizer step, trainer.py) replayed on
+    the C2 model with its default batch: SB = 4 objects x 3 source views of 128x128 (encoded inside every step with the
+    frozen ResNet-34 trunk: --freeze_enc), 128 rays per object (train.py:55), 64 coarse + 32 fine (16 depth) samples,
+    loss = MSE(coarse.rgb) + MSE(fine.rgb), loss.backward(), Adam(lr 1e-4).step().  Single GPU.
+    value = training rays/s.  roofline: GEMM FLOPs executed by the four MLP kernels of a step (forward, stash forward,
+    dX chain, weight-gradient GEMMs) / their HIP-event time, against the fp32 MFMA peak."""
+    import numpy as np
+    import torch
+
+    import pnyolo_pkg
+    pnyolo_pkg.load()
+    from pixel_nerf_yolo_amd import conf as pconf, synth
+    from pixel_nerf_yolo_amd.model import make_model
+    from pixel_nerf_yolo_amd.render import NeRFRenderer
+    from pixel_nerf_yolo_amd.util import gen_rays
+
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path for the product)"
+    dev = torch.device("cuda", 0)
+    SB, NSV, H, W, RB, KC, KF, KFD = 4, NS, 128, 128, 128, 64, 32, 16
+    steps = args.steps if args.steps is not None else 10
+    net = make_model(pconf.default_mv()["model"], stop_encoder_grad=True)
+    sd = {}
+    sd.update({"mlp_coarse." + k: v for k, v in synth.mlp_state(71).items()})
+    sd.update({"mlp_fine." + k: v for k, v in synth.mlp_state(72).items()})
+    sd.update(synth.resnet34_state(74, residual_gain=0.25))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    net = net.to(dev).train()
+    net.encoder.eval()                                             # train.py:70-73 (--freeze_enc)
+    for p_ in net.encoder.parameters():
+        p_.requires_grad_(False)
+    ren = NeRFRenderer(n_coarse=KC, n_fine=KF, n_fine_depth=KFD, depth_std=0.01, white_bkgd=True).train()
+    par = ren.bind_parallel(net, None).train()
+    opt = torch.optim.Adam([p_ for p_ in net.parameters() if p_.requires_grad], lr=1e-4)
+    rs = np.random.RandomState(5)
+    images = torch.from_numpy(np.stack([synth.images(80 + i, NSV, H, W) for i in range(SB)])).to(dev)     # (SB, NS, 3, H, W)
+    poses = torch.from_numpy(np.stack([synth.scene_cameras(NSV, radius=1.3 + 0.02 * i)[0] for i in range(SB)]))
+    focal = torch.full((SB,), FOCAL128)
+    tgt = torch.from_numpy(np.stack([synth.pose_spherical(120.0 + 10 * i, -20.0, 1.3) for i in range(SB)]))
+    all_rays = gen_rays(tgt, W, H, torch.tensor(FOCAL128), Z_NEAR, Z_FAR, device=dev).reshape(SB, -1, 8)
+    gt_all = torch.from_numpy(rs.uniform(0, 1, size=(SB, H * W, 3)).astype(np.float32)).to(dev)
+
+    def step(i):
+        pix = torch.from_numpy(np.random.RandomState(1000 + i).randint(0, H * W, size=(SB, RB))).to(dev)
+        rays = torch.gather(all_rays, 1, pix[..., None].expand(-1, -1, 8))
+        gt = torch.gather(gt_all, 1, pix[..., None].expand(-1, -1, 3))
+        net.encode(images, poses, focal)
+        out = par(rays, want_weights=True)
+        loss = torch.nn.functional.mse_loss(out["coarse"]["rgb"], gt) + torch.nn.functional.mse_loss(out["fine"]["rgb"], gt)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+
+    for i in range(max(args.warmup, 2)):
+        l0 = step(i)
+    torch.cuda.synchronize()
+    net.enable_kernel_timing(True)
+    k_ms, k_fl = [0.0] * 4, [0.0] * 4
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = step(100 + i)
+        f = net.last_mlp_stats(full=True)     # NOTE: reading event times waits for the step
+        b = net.last_backward_stats()
+        k_ms[0] += f["kernel_ms"]
+        k_fl[0] += f["flops"]
+        for j in range(3):
+            k_ms[1 + j] += b["kernel_ms"][j]
+            k_fl[1 + j] += b["flops"][j]
+        ff, fm = net.last_flush_stats()       # deferred mode: ONE weight-gradient GEMM per MLP over all scenes' tiles
+        k_ms[3] += fm
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    net.enable_kernel_timing(False)
+    assert bool(torch.isfinite(loss))
+    names = ["forward (projected latent)", "stash forward (reference order)", "dX chain", "weight-gradient GEMMs + reduce"]
+    # the scenes of the super-batch run on side streams, so per-kernel event times overlap: utilisation is priced
+    # against the step's WALL time (a lower bound on the kernels' own efficiency)
+    tot_ms, tot_fl = elapsed * 1e3, sum(k_fl)
+    out = {
+        "metric": "training rays/sec, 64+32 samples/ray, 3-view 128x128 conditioning", "value": SB * RB * steps / elapsed,
+        "unit": "rays/s", "n_gpus": 1, "steps": steps, "warmup": max(args.warmup, 2), "ms_per_step": elapsed / steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "train step of the C2 model: SB=4 objects x 3 views 128x128 (frozen ResNet34 trunk encoded "
+                               "every step), 128 rays/object, 64 coarse + 32 fine (16 depth), MSE coarse+fine, Adam",
+                   "rays_per_step": SB * RB},
+        "loss_first": float(l0), "loss_last": float(loss),
+        "roofline": {"bound": "mfma", "kernel": "MLP kernels of a training step", "achieved": tot_fl / (tot_ms * 1e-3) / 1e12,
+                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                     "frac_is": "GEMM FLOPs of the step's MLP kernels / step wall time (encode, sampling, composite, "
+                                "optimizer and host time included)", "traffic": None,
+                     "kernels": [{"name": n_, "event_ms_per_step_summed_over_concurrent_scenes": m_ / steps,
+                                  "gflop_per_step": f_ / steps / 1e9}
+                                 for n_, m_, f_ in zip(names, k_ms, k_fl)]},
+        "cpu_baseline": None,
+    }
+    print(json.dumps(out), flush=True)
+    return 0
+
+
 def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # before anything initialises HIP/HSA (dmabuf IPC for RCCL)
     ap = argparse.ArgumentParser()
@@ -113,6 +213,9 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2",
                     help="c2 = BASELINE.json configs[1] (default, the bench line); c3/c4/c5 = configs[2..4]")
     ap.add_argument("--no-reference-order", action="store_true", help="skip the --projection off leg of the N=1 line")
+    ap.add_argument("--mode", choices=["render", "train"], default="render",
+                    help="render (default, the bench line) or train: one optimisation step of the reference's trainer "
+                         "(train/trainlib/PixelNerfTrainer.py:58-156) on the C2 model")
     ap.add_argument("--describe", action="store_true", help="print the workload description and exit (no GPU)")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="multi-rank REHEARSAL on a one-GPU box: every rank uses device 0 and the exchange goes over gloo "
@@ -130,6 +233,8 @@ def main():
         return 0
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)
+    if args.mode == "train":
+        return train_main(args)
 
     import numpy as np
     import torch

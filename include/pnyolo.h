@@ -291,6 +291,24 @@ typedef struct pny_render_grads {
 int pny_render_backward(pny_scene* s, const float* rays_dev, int64_t n, const pny_render_opts* opts,
                         const pny_render_saved* saved, const pny_render_grads* grads, int accumulate, pny_stream stream);
 
+/* Deferred weight gradients.  A training batch holds several scenes (the reference's super-batch, SB objects x B rays,
+ * train/train.py:23) whose backward calls are independent until the weight gradients are summed.  With deferral enabled
+ * each pny_render_backward / pny_query_backward appends its tiles to a model-level stash (the calls of different scenes
+ * may then run concurrently on different streams: nothing shared is written) and pny_model_flush_weight_grads runs ONE
+ * weight-gradient GEMM per MLP over all of them (larger K per workgroup, one reduction).  coarse_tiles / fine_tiles =
+ * 64-sample tiles to reserve for evaluations of mlp_coarse / mlp_fine: sum over the calls of ceil(points / 64).
+ * PNY_ERR_ARG when the reservation exceeds the stash budget (the caller then stays in immediate mode).  The flush must be
+ * ordered after the scenes' calls by the caller (same stream, or events). */
+int pny_model_defer_weight_grads(pny_model* m, int enable, int ns, int64_t coarse_tiles, int64_t fine_tiles);
+int pny_model_flush_weight_grads(pny_model* m, int accumulate, pny_stream stream);
+/* GEMM FLOPs and HIP-event time of the last flush. */
+int pny_model_last_flush_stats(pny_model* m, double* flops, double* kernel_ms);
+
+/* Introspection for bench.py --mode train: GEMM FLOPs (2/MAC, unpadded) and HIP-event times (pny_scene_enable_timing)
+ * of the three MLP kernels of the last pny_render_backward / pny_query_backward on this scene:
+ * [0] stash forward (reference operation order), [1] dX chain, [2] weight-gradient GEMMs (+ reduction). */
+int pny_scene_last_backward_stats(pny_scene* s, double flops[3], double kernel_ms[3]);
+
 #ifdef __cplusplus
 }
 #endif

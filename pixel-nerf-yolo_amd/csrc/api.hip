@@ -207,6 +207,16 @@ void pny_model_destroy(pny_model* m) {
     if (!m) return;
     m->packed.release();
     m->repack_jobs.release();
+    for (int w = 0; w < 2; ++w) {
+        m->dx_stash[w].release();
+        m->ddy_stash[w].release();
+        m->d_partial[w].release();
+        m->d_bias[w].release();
+        m->d_tables[w].release();
+        m->d_stage[w].release();
+    }
+    for (auto& e : m->flush_ev)
+        if (e) (void)hipEventDestroy(e);
     m->enc.release();
     for (float* p : m->zproj_allocs) (void)hipFree(p);
     delete m;
@@ -395,6 +405,8 @@ void pny_scene_destroy(pny_scene* s) {
                       &s->sel_tmp, &s->gdepth_tmp})
         b->release();
     for (auto e : s->ev) (void)hipEventDestroy(e);
+    for (auto e : s->bev) (void)hipEventDestroy(e);
+    s->table_stage.release();
     if (s->order_ev) (void)hipEventDestroy(s->order_ev);
     delete s;
 }

@@ -38,6 +38,51 @@ struct DevBuf {
 
 int fail(int code, const std::string& msg);
 
+// Small host -> device parameter tables that change from call to call (work lists of the weight-gradient GEMMs): staged
+// through a pinned block; the block is rewritten only after the previous asynchronous copy out of it has executed.
+struct PinnedStage {
+    void* host = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;
+    bool pending = false;
+    int prepare(size_t bytes) {   // returns 0 and a writable block of >= bytes
+        if (pending) {
+            hipError_t e = hipEventSynchronize(ev);
+            if (e != hipSuccess) return hip_fail(e, "hipEventSynchronize(table stage)");
+            pending = false;
+        }
+        if (bytes > cap) {
+            if (host) (void)hipHostFree(host);
+            host = nullptr;
+            cap = 0;
+            hipError_t e = hipHostMalloc(&host, bytes * 2, hipHostMallocDefault);
+            if (e != hipSuccess) return hip_fail(e, "hipHostMalloc(table stage)");
+            cap = bytes * 2;
+        }
+        if (!ev) {
+            hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e != hipSuccess) return hip_fail(e, "hipEventCreate(table stage)");
+        }
+        return 0;
+    }
+    int upload(void* dst_dev, size_t bytes, hipStream_t st) {
+        hipError_t e = hipMemcpyAsync(dst_dev, host, bytes, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(table stage)");
+        e = hipEventRecord(ev, st);
+        if (e != hipSuccess) return hip_fail(e, "hipEventRecord(table stage)");
+        pending = true;
+        return 0;
+    }
+    void release() {
+        if (host) (void)hipHostFree(host);
+        if (ev) (void)hipEventDestroy(ev);
+        host = nullptr;
+        ev = nullptr;
+        cap = 0;
+        pending = false;
+    }
+};
+
 // One packed sub-buffer of the model and how to rebuild it from the state_dict tensor(s) it came from: recorded by
 // pny_model_finalize, replayed on the device by pny_model_refresh (pack.hip).
 struct RepackEntry {
@@ -76,6 +121,16 @@ struct pny_model {
     long long repack_max_elems = 0;
     bool repack_ready = false;
     std::vector<struct pny_scene*> scenes;   // scenes created on this model (stream ordering of a refresh)
+    // Deferred weight gradients (pny_model_defer_weight_grads): the scenes' backward calls append their tiles to these
+    // model-level stashes ([0] mlp_coarse, [1] mlp_fine) and ONE weight-gradient GEMM per MLP runs at the flush.
+    bool defer = false;
+    int defer_ns = 0;
+    DevBuf dx_stash[2], ddy_stash[2], d_partial[2], d_bias[2], d_tables[2];
+    PinnedStage d_stage[2];
+    long long defer_cap[2] = {0, 0}, defer_used[2] = {0, 0};
+    hipEvent_t flush_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    double flush_flops = 0.0;
+    int flush_launches = 0;
     EncoderWeights enc;                       // folded conv+bn (encoder.h)
     bool has_encoder = false;
     // lin_z[0..nvb) of the coarse / fine MLP stacked into one (nvb*512 x d_latent) pixel-wise map
@@ -109,7 +164,11 @@ struct pny_scene {
     // stream the last call on this scene was enqueued on (see enter_stream)
     // training workspace (train_api.hip)
     DevBuf x_stash, dy_stash, dw_partial, dw_bias, dw_tables, d_samp, out_tmp, dz_tmp, sel_tmp, gdepth_tmp;
-    std::vector<char> table_host;
+    PinnedStage table_stage;
+    // HIP-event timing of the backward kernels of the last backward call (enable_timing): per MLP pass 4 events
+    std::vector<hipEvent_t> bev;
+    int bev_used = 0;
+    double bwd_flops[3] = {0.0, 0.0, 0.0};   // stash forward, dX chain, weight-gradient GEMMs
     hipStream_t last_stream = nullptr;
     bool has_last_stream = false;
     hipEvent_t order_ev = nullptr;

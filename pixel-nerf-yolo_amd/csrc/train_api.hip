@@ -149,6 +149,41 @@ size_t stash_budget_bytes() {
     return v;
 }
 
+// Weight-gradient GEMMs over n_tiles tiles of the two stashes + deterministic split reduction into the bound gradients.
+int run_weight_grads(TrainPlan& plan, int n_tiles, const float* x_stash, const float* dy_stash, DevBuf& partial, DevBuf& bias,
+                     DevBuf& tables, PinnedStage& stage, int accumulate, hipStream_t st) {
+    const int cus = mlp_max_grid(MLP_8x64);
+    std::vector<DwItem> items;
+    long long part_floats = 0, bias_floats = 0;
+    build_items(plan, n_tiles, cus, items, &part_floats, &bias_floats);
+    int rc;
+    if ((rc = partial.reserve((size_t)part_floats * sizeof(float)))) return rc;
+    if ((rc = bias.reserve((size_t)bias_floats * sizeof(float)))) return rc;
+    const size_t jb_bytes = plan.jobs.size() * sizeof(DwJob), it_bytes = items.size() * sizeof(DwItem),
+                 tg_bytes = plan.targets.size() * sizeof(DwTarget);
+    const size_t o_items = (jb_bytes + 255) & ~(size_t)255, o_targets = o_items + ((it_bytes + 255) & ~(size_t)255);
+    const size_t total = o_targets + tg_bytes;
+    // NOTE: a grown device table is only safe because growth happens before any kernel of this call uses it and after
+    // the previous call's kernels (same stream) were enqueued: hipFree of DevBuf::reserve synchronises the device
+    if ((rc = tables.reserve(total))) return rc;
+    if ((rc = stage.prepare(total))) return rc;
+    char* h = reinterpret_cast<char*>(stage.host);
+    memcpy(h, plan.jobs.data(), jb_bytes);
+    memcpy(h + o_items, items.data(), it_bytes);
+    memcpy(h + o_targets, plan.targets.data(), tg_bytes);
+    if ((rc = stage.upload(tables.p, total, st))) return rc;
+    char* tb = reinterpret_cast<char*>(tables.p);
+    launch_dw_gemm(reinterpret_cast<const DwJob*>(tb), reinterpret_cast<const DwItem*>(tb + o_items), (int)items.size(), x_stash,
+                   dy_stash, plan.lay.x_tile, plan.lay.dy_tile, partial.f(), bias.f(), st);
+    PNY_HIP(hipGetLastError());
+    long long max_elems = 0;
+    for (const DwTarget& t : plan.targets) max_elems = std::max(max_elems, (long long)t.rows * t.cols + t.rows);
+    launch_dw_reduce(reinterpret_cast<const DwTarget*>(tb + o_targets), (int)plan.targets.size(), max_elems, partial.f(), bias.f(),
+                     accumulate, st);
+    PNY_HIP(hipGetLastError());
+    return 0;
+}
+
 // Backward of one MLP evaluation over n_points query points (mode 0: xyz / dirs; mode 1: rays + z with K samples per
 // ray): d_out (n_points, d_out) -> bound parameter gradients.  Points are processed in chunks that fit the stash.
 // dz_sel / dz_out (mode 1 only, optional): per ray kfd sample indices (ray * K + position, or -1) whose depth gradient
@@ -172,10 +207,47 @@ int mlp_backward(pny_scene* s, int mode, const float* xyz, const float* dirs, co
     const int cus = mlp_max_grid(MLP_8x64);
     int rc;
     const long long chunk_tiles_max = (chunk_pts + 63) / 64;
-    if ((rc = s->x_stash.reserve((size_t)chunk_tiles_max * plan.lay.x_tile * sizeof(float)))) return rc;
-    if ((rc = s->dy_stash.reserve((size_t)chunk_tiles_max * plan.lay.dy_tile * sizeof(float)))) return rc;
+    // Deferred mode: this call's tiles are appended to the model-level stash of its MLP; the weight-gradient GEMM runs
+    // once over every scene's tiles at pny_model_flush_weight_grads
+    const int which = fine_w ? 1 : 0;
+    float* x_base = nullptr;
+    float* dy_base = nullptr;
+    if (m->defer) {
+        const long long tiles = (n_points + 63) / 64;
+        if (s->ns != m->defer_ns) return fail(PNY_ERR_STATE, "deferred weight gradients: scene view count differs from the reservation");
+        if (m->defer_used[which] + tiles > m->defer_cap[which])
+            return fail(PNY_ERR_STATE, "deferred weight gradients: more tiles than pny_model_defer_weight_grads reserved");
+        chunk_pts = n_points;   // one chunk: the reservation was made against the budget
+        x_base = m->dx_stash[which].f() + m->defer_used[which] * plan.lay.x_tile;
+        dy_base = m->ddy_stash[which].f() + m->defer_used[which] * plan.lay.dy_tile;
+        m->defer_used[which] += tiles;
+    } else {
+        if ((rc = s->x_stash.reserve((size_t)chunk_tiles_max * plan.lay.x_tile * sizeof(float)))) return rc;
+        if ((rc = s->dy_stash.reserve((size_t)chunk_tiles_max * plan.lay.dy_tile * sizeof(float)))) return rc;
+        x_base = s->x_stash.f();
+        dy_base = s->dy_stash.f();
+    }
     if ((rc = s->out_tmp.reserve((size_t)chunk_pts * d.d_out * sizeof(float)))) return rc;
-    std::vector<DwItem> items;
+    auto stamp = [&]() -> int {   // kernel timing for bench.py (pny_scene_enable_timing)
+        if (!s->timing) return 0;
+        if ((int)s->bev.size() <= s->bev_used) {
+            hipEvent_t e;
+            PNY_HIP(hipEventCreate(&e));
+            s->bev.push_back(e);
+        }
+        PNY_HIP(hipEventRecord(s->bev[s->bev_used++], st));
+        return 0;
+    };
+    {   // GEMM FLOPs (2 per MAC, unpadded) of the three kernels, per query point
+        const int nvb_ = view_blocks(d), npost_ = d.n_blocks - nvb_, d_in_ = 3 + 6 * d.num_freqs + 3;
+        const double per_view_f = (double)d_in_ * HID + (double)nvb_ * s->L * HID + 2.0 * nvb_ * HID * HID;
+        const double post_f = 2.0 * npost_ * HID * HID + (double)HID * d.d_out;
+        const double fwd = 2.0 * (s->ns * per_view_f + post_f);
+        const double chain = 2.0 * (s->ns * 2.0 * nvb_ * HID * HID + 2.0 * npost_ * HID * HID + (double)HID * d.d_out);
+        s->bwd_flops[0] += fwd * (double)n_points;
+        s->bwd_flops[1] += chain * (double)n_points;
+        s->bwd_flops[2] += fwd * (double)n_points;   // every forward GEMM has one weight-gradient GEMM of the same size
+    }
     const float* zp_maps = nullptr;
     if (dz_sel && view_blocks(d) > 0) {
         if ((rc = ensure_projection(s, fine_w ? 1 : 0, 0, st, &zp_maps, true))) return rc;
@@ -190,11 +262,13 @@ int mlp_backward(pny_scene* s, int mode, const float* xyz, const float* dirs, co
                                 mode == 1 ? rays + (p0 / K) * 8 : nullptr, mode == 1 ? z + p0 : nullptr, K, np, coarse,
                                 s->out_tmp.f(), &a)))
             return rc;
-        a.stash_x = s->x_stash.f();
+        a.stash_x = x_base;
         a.lay = plan.lay;
         const int grid = std::min(cus, n_tiles);
+        if ((rc = stamp())) return rc;
         launch_mlp_stash(a, grid, st);
         PNY_HIP(hipGetLastError());
+        if ((rc = stamp())) return rc;
         // 2. dX chain
         const MlpWeightsT& wt = fine_w ? m->fine_t : m->coarse_t;
         BwdArgs b;
@@ -206,8 +280,8 @@ int mlp_backward(pny_scene* s, int mode, const float* xyz, const float* dirs, co
         }
         b.w_base = m->packed.f();
         b.w_bytes = (unsigned)m->packed.bytes;
-        b.x_stash = s->x_stash.f();
-        b.dy_stash = s->dy_stash.f();
+        b.x_stash = x_base;
+        b.dy_stash = dy_base;
         b.lay = plan.lay;
         b.out = s->out_tmp.f();
         b.d_out_grad = d_out + p0 * d.d_out;
@@ -220,11 +294,12 @@ int mlp_backward(pny_scene* s, int mode, const float* xyz, const float* dirs, co
         b.yolo = d.yolo;
         launch_mlp_bwd(b, grid, st);
         PNY_HIP(hipGetLastError());
+        if ((rc = stamp())) return rc;
         // 2b. gradient w.r.t. the depths of the selected samples through the MLP inputs (fine pass of a render)
         if (dz_sel && mode == 1) {
             DzArgs dz;
             memset(&dz, 0, sizeof(dz));
-            dz.dy_stash = s->dy_stash.f();
+            dz.dy_stash = dy_base;
             dz.lay = plan.lay;
             dz.sel = dz_sel + (p0 / K) * kfd;
             dz.n_sel = (int)((np / K) * kfd);
@@ -252,31 +327,11 @@ int mlp_backward(pny_scene* s, int mode, const float* xyz, const float* dirs, co
             PNY_HIP(hipGetLastError());
         }
         // 3. weight-gradient GEMMs over the two stashes + deterministic split reduction into the bound gradients
-        long long part_floats = 0, bias_floats = 0;
-        build_items(plan, n_tiles, cus, items, &part_floats, &bias_floats);
-        if ((rc = s->dw_partial.reserve((size_t)part_floats * sizeof(float)))) return rc;
-        if ((rc = s->dw_bias.reserve((size_t)bias_floats * sizeof(float)))) return rc;
-        const size_t jb_bytes = plan.jobs.size() * sizeof(DwJob), it_bytes = items.size() * sizeof(DwItem),
-                     tg_bytes = plan.targets.size() * sizeof(DwTarget);
-        const size_t o_items = (jb_bytes + 255) & ~(size_t)255, o_targets = o_items + ((it_bytes + 255) & ~(size_t)255);
-        if ((rc = s->dw_tables.reserve(o_targets + tg_bytes))) return rc;
-        // the tables are small (KBs) and change with the chunk's tile count: staged with stream-ordered copies from a
-        // host block that lives until the copies have executed (the scene keeps it)
-        s->table_host.resize(o_targets + tg_bytes);
-        memcpy(s->table_host.data(), plan.jobs.data(), jb_bytes);
-        memcpy(s->table_host.data() + o_items, items.data(), it_bytes);
-        memcpy(s->table_host.data() + o_targets, plan.targets.data(), tg_bytes);
-        PNY_HIP(hipStreamSynchronize(st));  // (v1) the previous chunk's kernels still read the tables
-        PNY_HIP(hipMemcpyAsync(s->dw_tables.p, s->table_host.data(), o_targets + tg_bytes, hipMemcpyHostToDevice, st));
-        char* tb = reinterpret_cast<char*>(s->dw_tables.p);
-        launch_dw_gemm(reinterpret_cast<const DwJob*>(tb), reinterpret_cast<const DwItem*>(tb + o_items), (int)items.size(),
-                       s->x_stash.f(), s->dy_stash.f(), plan.lay.x_tile, plan.lay.dy_tile, s->dw_partial.f(), s->dw_bias.f(), st);
-        PNY_HIP(hipGetLastError());
-        long long max_elems = 0;
-        for (const DwTarget& t : plan.targets) max_elems = std::max(max_elems, (long long)t.rows * t.cols + t.rows);
-        launch_dw_reduce(reinterpret_cast<const DwTarget*>(tb + o_targets), (int)plan.targets.size(), max_elems,
-                         s->dw_partial.f(), s->dw_bias.f(), (accumulate || p0 > 0) ? 1 : 0, st);
-        PNY_HIP(hipGetLastError());
+        if (!m->defer &&
+            (rc = run_weight_grads(plan, n_tiles, x_base, dy_base, s->dw_partial, s->dw_bias, s->dw_tables, s->table_stage,
+                                   (accumulate || p0 > 0) ? 1 : 0, st)))
+            return rc;
+        if ((rc = stamp())) return rc;
     }
     return 0;
 }
@@ -294,6 +349,74 @@ int pny_model_bind_grad(pny_model* m, const char* name, float* grad_dev) {
     return PNY_OK;
 }
 
+int pny_model_defer_weight_grads(pny_model* m, int enable, int ns, int64_t coarse_tiles, int64_t fine_tiles) {
+    if (!m) return fail(PNY_ERR_ARG, "pny_model_defer_weight_grads: null model");
+    m->defer = false;
+    m->defer_used[0] = m->defer_used[1] = 0;
+    if (!enable) return PNY_OK;
+    if (ns < 1 || ns > MAX_VIEWS || coarse_tiles < 0 || fine_tiles < 0) return fail(PNY_ERR_ARG, "pny_model_defer_weight_grads: bad argument");
+    PNY_HIP(hipSetDevice(m->desc.device));
+    TrainPlan plan = build_plan(m, ns, m->desc.d_latent, "mlp_coarse.");   // the layout does not depend on the MLP
+    const size_t tile_bytes = (size_t)(plan.lay.x_tile + plan.lay.dy_tile) * sizeof(float);
+    if ((size_t)(coarse_tiles + fine_tiles) * tile_bytes > stash_budget_bytes())
+        return fail(PNY_ERR_ARG, "pny_model_defer_weight_grads: reservation exceeds the stash budget (PNYOLO_STASH_GB)");
+    const int64_t tiles[2] = {coarse_tiles, fine_tiles};
+    int rc;
+    for (int w = 0; w < 2; ++w) {
+        if ((rc = m->dx_stash[w].reserve((size_t)tiles[w] * plan.lay.x_tile * sizeof(float)))) return rc;
+        if ((rc = m->ddy_stash[w].reserve((size_t)tiles[w] * plan.lay.dy_tile * sizeof(float)))) return rc;
+        m->defer_cap[w] = tiles[w];
+    }
+    m->defer_ns = ns;
+    m->defer = true;
+    return PNY_OK;
+}
+
+int pny_model_flush_weight_grads(pny_model* m, int accumulate, pny_stream stream) {
+    if (!m) return fail(PNY_ERR_ARG, "pny_model_flush_weight_grads: null model");
+    if (!m->defer) return fail(PNY_ERR_STATE, "pny_model_flush_weight_grads: not in deferred mode");
+    PNY_HIP(hipSetDevice(m->desc.device));
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    m->flush_flops = 0.0;
+    m->flush_launches = 0;
+    for (int i = 0; i < 4; ++i)
+        if (!m->flush_ev[i]) PNY_HIP(hipEventCreate(&m->flush_ev[i]));
+    const pny_model_desc& d = m->desc;
+    const int nvb_ = view_blocks(d), npost_ = d.n_blocks - nvb_, d_in_ = 3 + 6 * d.num_freqs + 3;
+    const double per_view_f = (double)d_in_ * HID + (double)nvb_ * d.d_latent * HID + 2.0 * nvb_ * HID * HID;
+    const double fwd = 2.0 * (m->defer_ns * per_view_f + 2.0 * npost_ * HID * HID + (double)HID * d.d_out);
+    for (int w = 0; w < 2; ++w) {
+        PNY_HIP(hipEventRecord(m->flush_ev[2 * w], st));
+        if (m->defer_used[w] > 0) {
+            TrainPlan plan = build_plan(m, m->defer_ns, d.d_latent, w ? "mlp_fine." : "mlp_coarse.");
+            if ((rc = run_weight_grads(plan, (int)m->defer_used[w], m->dx_stash[w].f(), m->ddy_stash[w].f(), m->d_partial[w],
+                                       m->d_bias[w], m->d_tables[w], m->d_stage[w], accumulate, st)))
+                return rc;
+            m->flush_flops += fwd * 64.0 * (double)m->defer_used[w];
+            m->flush_launches += 1;
+        }
+        PNY_HIP(hipEventRecord(m->flush_ev[2 * w + 1], st));
+        m->defer_used[w] = 0;
+    }
+    return PNY_OK;
+}
+
+int pny_model_last_flush_stats(pny_model* m, double* flops, double* kernel_ms) {
+    if (!m) return fail(PNY_ERR_ARG, "pny_model_last_flush_stats: null model");
+    if (flops) *flops = m->flush_flops;
+    if (kernel_ms) {
+        *kernel_ms = 0.0;
+        for (int w = 0; w < 2 && m->flush_ev[0]; ++w) {
+            PNY_HIP(hipEventSynchronize(m->flush_ev[2 * w + 1]));
+            float ms = 0.f;
+            PNY_HIP(hipEventElapsedTime(&ms, m->flush_ev[2 * w], m->flush_ev[2 * w + 1]));
+            *kernel_ms += ms;
+        }
+    }
+    return PNY_OK;
+}
+
 int pny_query_backward(pny_scene* s, const float* xyz_dev, const float* viewdirs_dev, int64_t n, int coarse,
                        const float* d_out_dev, int accumulate, pny_stream stream) {
     int rc;
@@ -301,6 +424,8 @@ int pny_query_backward(pny_scene* s, const float* xyz_dev, const float* viewdirs
     if (n < 0 || (n > 0 && (!xyz_dev || !viewdirs_dev || !d_out_dev))) return fail(PNY_ERR_ARG, "pny_query_backward: bad argument");
     PNY_HIP(hipSetDevice(s->m->desc.device));
     if ((rc = enter_stream(s, (hipStream_t)stream))) return rc;
+    s->bev_used = 0;
+    s->bwd_flops[0] = s->bwd_flops[1] = s->bwd_flops[2] = 0.0;
     return mlp_backward(s, 0, xyz_dev, viewdirs_dev, nullptr, nullptr, 1, n, coarse, d_out_dev, accumulate, (hipStream_t)stream);
 }
 
@@ -330,6 +455,8 @@ int pny_render_backward(pny_scene* s, const float* rays_dev, int64_t n, const pn
     PNY_HIP(hipSetDevice(s->m->desc.device));
     hipStream_t st = (hipStream_t)stream;
     if ((rc = enter_stream(s, st))) return rc;
+    s->bev_used = 0;
+    s->bwd_flops[0] = s->bwd_flops[1] = s->bwd_flops[2] = 0.0;
     if ((rc = s->d_samp.reserve((size_t)n * kt * 4 * sizeof(float)))) return rc;
     const bool same_mlp = !s->m->desc.has_fine || !s->m->use_fine;  // both passes differentiate mlp_coarse
     bool first = true;
@@ -372,6 +499,27 @@ int pny_render_backward(pny_scene* s, const float* rays_dev, int64_t n, const pn
         if ((rc = mlp_backward(s, 1, nullptr, nullptr, rays_dev, sv->z_coarse, kc, (long long)n * kc, 1, s->d_samp.f(),
                                (accumulate || (same_mlp && !first)) ? 1 : 0, st)))
             return rc;
+    }
+    return PNY_OK;
+}
+
+int pny_scene_last_backward_stats(pny_scene* s, double flops[3], double kernel_ms[3]) {
+    if (!s) return fail(PNY_ERR_ARG, "pny_scene_last_backward_stats: null scene");
+    for (int i = 0; i < 3; ++i) {
+        if (flops) flops[i] = s->bwd_flops[i];
+        if (kernel_ms) kernel_ms[i] = 0.0;
+    }
+    if (kernel_ms && s->timing) {
+        // events come in groups of 4 per chunk: before the stash forward, after it, after the chain, after the GEMMs + reduce
+        // (the chunk's sample-depth kernel, when present, is counted with the GEMMs)
+        for (int i = 0; i + 3 < s->bev_used; i += 4) {
+            PNY_HIP(hipEventSynchronize(s->bev[i + 3]));
+            for (int k = 0; k < 3; ++k) {
+                float ms = 0.f;
+                PNY_HIP(hipEventElapsedTime(&ms, s->bev[i + k], s->bev[i + k + 1]));
+                kernel_ms[k] += ms;
+            }
+        }
     }
     return PNY_OK;
 }

@@ -376,6 +376,19 @@ class PixelNeRFNet(nn.Module):
             return dict(flops=fl, flops_reference=ref, kernel_ms=ms, launches=n, projected=proj)
         return fl, ms, n
 
+    def last_backward_stats(self):
+        """dict(flops=[3], kernel_ms=[3]) of the last backward call, summed over scenes: stash forward, dX chain,
+        weight-gradient GEMMs (include/pnyolo.h pny_scene_last_backward_stats)."""
+        L = _lib.load()
+        fl, ms = [0.0] * 3, [0.0] * 3
+        for s in self._h_scenes[: max(self.num_objs, 1)]:
+            a, b = (C.c_double * 3)(), (C.c_double * 3)()
+            check(L.pny_scene_last_backward_stats(s, a, b))
+            for i in range(3):
+                fl[i] += a[i]
+                ms[i] += b[i]
+        return dict(flops=fl, kernel_ms=ms)
+
     # ---------------------------------------------------------------- training plumbing
     def trainable_mlp_parameters(self):
         """[(state_dict name, Parameter)] of the MLP parameters that require grad, in a fixed order."""
@@ -405,6 +418,33 @@ class PixelNeRFNet(nn.Module):
             grads.append(g)
         self._bound_grads = grads   # keep the buffers alive while they are bound
         return grads
+
+    def fork_streams(self, n):
+        """n stream contexts for n independent scenes: side streams ordered behind the current stream (None = stay on the
+        current stream when there is a single scene or PNYOLO_SCENE_STREAMS=0)."""
+        import os
+        if n <= 1 or os.environ.get("PNYOLO_SCENE_STREAMS", "1") == "0":
+            return [None] * n
+        dev = self._device()
+        pool = getattr(self, "_side_streams", None)
+        if pool is None or len(pool) < n or pool[0].device != dev:
+            pool = self._side_streams = [torch.cuda.Stream(dev) for _ in range(n)]
+        main = torch.cuda.current_stream(dev)
+        for st in pool[:n]:
+            st.wait_stream(main)
+        return pool[:n]
+
+    def join_streams(self, streams):
+        main = torch.cuda.current_stream(self._device())
+        for st in streams:
+            if st is not None:
+                main.wait_stream(st)
+
+    def last_flush_stats(self):
+        """(GEMM FLOPs, kernel ms) of the last deferred weight-gradient flush (pny_model_last_flush_stats)."""
+        a, b = C.c_double(), C.c_double()
+        check(_lib.load().pny_model_last_flush_stats(self._h_model, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def invalidate_weights(self):
         """Force a re-upload of the parameters at the next call.  Needed after writes that PyTorch does not version:
@@ -459,8 +499,12 @@ class PixelNeRFNet(nn.Module):
             assert latent.dim() == 4 and latent.shape[0] == SB * NS, "latent must be (SB*NS, L, Hl, Wl)"
         else:
             images = images.detach().to(dev, torch.float32).contiguous()
+        scenes = [self._scene(sb) for sb in range(SB)]
+        streams = self.fork_streams(SB)       # the scenes' trunks are independent: one side stream each
         for sb in range(SB):
-            s = self._scene(sb)
+          with torch.cuda.stream(streams[sb]):
+            s = scenes[sb]
+            st = stream_of(dev)
             # per-scene focal / c rows: batch 1 broadcasts, batch SB is per scene, batch SB*NS per view
             def rows(t):
                 if t.shape[0] == 1:
@@ -479,6 +523,7 @@ class PixelNeRFNet(nn.Module):
             else:
                 img = images[sb * NS:(sb + 1) * NS]
                 check(L.pny_scene_encode(s, ptr(img), NS, H, W, st))
+        self.join_streams(streams)
 
     def latent(self, sb=0):
         """(NS, L, Hl, Wl) latent of scene `sb` as the reference keeps it in encoder.latent."""

@@ -61,32 +61,44 @@ class _RenderFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_rgb_c, g_depth_c, g_w_c, g_rgb_f, g_depth_f, g_w_f):
-        model, sv = ctx.model, ctx.saved
+        model, sv, ren = ctx.model, ctx.saved, ctx.renderer
         L = _lib.load()
         dev = model._device()
         grads = model.bind_mlp_grads()            # zeroed fp32 buffers, one per trainable MLP parameter, bound by name
-        st = stream_of(dev)
         SB, B = sv["rays"].shape[0], sv["rays"].shape[1]
+        kc = sv["z_coarse"].shape[-1]
+        kt = sv["z_fine"].shape[-1] if ctx.has_fine else 0
 
-        def g(t, sb):
+        def prep(t):
             if t is None or t.numel() == 0:
                 return None
-            t = t.detach().to(dev, torch.float32).contiguous()
-            return t[sb].contiguous()
+            return t.detach().to(dev, torch.float32).contiguous()
 
-        keep = []
+        ups = [prep(x) for x in (g_rgb_c, g_depth_c, g_w_c, g_rgb_f, g_depth_f, g_w_f)]
+        # Scenes of a super-batch are independent until their weight gradients are summed: with the tiles of all scenes
+        # in one model-level stash (pny_model_defer_weight_grads) the per-scene calls run on side streams and ONE
+        # weight-gradient GEMM per MLP follows; if the reservation does not fit the stash budget, scene after scene.
+        tiles = lambda pts: -(-pts // 64)
+        fine_mlp = model.mlp_fine is not None
+        ct = tiles(B * kc) + (tiles(B * kt) if (ctx.has_fine and not fine_mlp) else 0)
+        ft = tiles(B * kt) if (ctx.has_fine and fine_mlp) else 0
+        deferred = SB > 1 and L.pny_model_defer_weight_grads(model._h_model, 1, model.num_views_per_obj, SB * ct, SB * ft) == 0
+        streams = model.fork_streams(SB) if deferred else [None] * SB
         for sb in range(SB):
-            s_ = _lib.RenderSaved(z_coarse=sv["z_coarse"][sb].data_ptr(), sample_coarse=sv["sample_coarse"][sb].data_ptr())
-            if not getattr(ctx.renderer, "_detach_fine_depth", False):   # test aid: treat the depth samples as constants
-                s_.depth_coarse = sv["depth_coarse"][sb].data_ptr()
-            if ctx.has_fine:
-                s_.z_fine = sv["z_fine"][sb].data_ptr()
-                s_.sample_fine = sv["sample_fine"][sb].data_ptr()
-            parts = [g(x, sb) for x in (g_rgb_c, g_depth_c, g_w_c, g_rgb_f, g_depth_f, g_w_f)]
-            keep.append(parts)
-            gr = _lib.RenderGrads(*[None if p is None else p.data_ptr() for p in parts])
-            check(L.pny_render_backward(model._scene(sb), ptr(sv["rays"][sb]), B, C.byref(sv["opts"][sb]), C.byref(s_),
-                                        C.byref(gr), 1, st))
+            with torch.cuda.stream(streams[sb]):
+                s_ = _lib.RenderSaved(z_coarse=sv["z_coarse"][sb].data_ptr(), sample_coarse=sv["sample_coarse"][sb].data_ptr())
+                if not getattr(ren, "_detach_fine_depth", False):   # test aid: treat the depth samples as constants
+                    s_.depth_coarse = sv["depth_coarse"][sb].data_ptr()
+                if ctx.has_fine:
+                    s_.z_fine = sv["z_fine"][sb].data_ptr()
+                    s_.sample_fine = sv["sample_fine"][sb].data_ptr()
+                gr = _lib.RenderGrads(*[None if p is None else p[sb].data_ptr() for p in ups])
+                check(L.pny_render_backward(model._scene(sb), ptr(sv["rays"][sb]), B, C.byref(sv["opts"][sb]), C.byref(s_),
+                                            C.byref(gr), 1, stream_of(dev)))
+        if deferred:
+            model.join_streams(streams)
+            check(L.pny_model_flush_weight_grads(model._h_model, 1, stream_of(dev)))
+            check(L.pny_model_defer_weight_grads(model._h_model, 0, 0, 0, 0))
         return (None, None, None, None, None) + tuple(grads)
 
 
@@ -182,42 +194,44 @@ class NeRFRenderer(torch.nn.Module):
                     saved[k] = extra.pop(k, saved[k])   # a debug capture of the same buffer: share it
         draws, self.draws = self.draws, None
         self._calls += 1
-        st = stream_of(dev)
         keep = []
+        streams = model.fork_streams(SB)      # scenes are independent: one side stream each (None = current stream)
         for sb in range(SB):
-            o = RenderOpts(n_coarse=kc, n_fine=kf, n_fine_depth=kfd, depth_std=float(self.depth_std),
-                           white_bkgd=int(bool(self.white_bkgd)), lindisp=int(bool(self.lindisp)),
-                           seed=(self.base_seed + 7919 * self._calls + sb) & 0xFFFFFFFFFFFFFFFF)
-            if draws is not None:
-                def dev_draw(name, cols):
-                    if cols == 0:
-                        return None
-                    t = torch.as_tensor(draws[name], dtype=torch.float32).reshape(SB, B, cols)[sb].to(dev).contiguous()
-                    keep.append(t)
-                    return t.data_ptr()
-                o.u_coarse_dev = dev_draw("u_coarse", kc)
-                o.u_fine_dev = dev_draw("u_fine", kf - kfd)
-                o.u_fine2_dev = dev_draw("u_fine2", kf - kfd)
-                o.g_depth_dev = dev_draw("g_depth", kfd)
-            out = RenderOut()
-            out.rgb_coarse = res["coarse"]["rgb"][sb].data_ptr()
-            out.depth_coarse = res["coarse"]["depth"][sb].data_ptr()
-            if want_weights:
-                out.weights_coarse = res["coarse"]["weights"][sb].data_ptr()
-            if use_fine:
-                out.rgb_fine = res["fine"]["rgb"][sb].data_ptr()
-                out.depth_fine = res["fine"]["depth"][sb].data_ptr()
+            with torch.cuda.stream(streams[sb]):
+                o = RenderOpts(n_coarse=kc, n_fine=kf, n_fine_depth=kfd, depth_std=float(self.depth_std),
+                               white_bkgd=int(bool(self.white_bkgd)), lindisp=int(bool(self.lindisp)),
+                               seed=(self.base_seed + 7919 * self._calls + sb) & 0xFFFFFFFFFFFFFFFF)
+                if draws is not None:
+                    def dev_draw(name, cols):
+                        if cols == 0:
+                            return None
+                        t = torch.as_tensor(draws[name], dtype=torch.float32).reshape(SB, B, cols)[sb].to(dev).contiguous()
+                        keep.append(t)
+                        return t.data_ptr()
+                    o.u_coarse_dev = dev_draw("u_coarse", kc)
+                    o.u_fine_dev = dev_draw("u_fine", kf - kfd)
+                    o.u_fine2_dev = dev_draw("u_fine2", kf - kfd)
+                    o.g_depth_dev = dev_draw("g_depth", kfd)
+                out = RenderOut()
+                out.rgb_coarse = res["coarse"]["rgb"][sb].data_ptr()
+                out.depth_coarse = res["coarse"]["depth"][sb].data_ptr()
                 if want_weights:
-                    out.weights_fine = res["fine"]["weights"][sb].data_ptr()
-            for name, buf in extra.items():
-                setattr(out, name, buf[sb].data_ptr())
-            if save:
-                for name in ("z_coarse", "sample_coarse", "z_fine", "sample_fine"):
-                    if name in saved:
-                        setattr(out, name, saved[name][sb].data_ptr())
-                saved["opts"].append(o)
-                saved["keep"] = keep   # the explicit draws are read again by the backward (depth samples)
-            check(L.pny_render(model._scene(sb), ptr(rays[sb]), B, C.byref(o), C.byref(out), st))
+                    out.weights_coarse = res["coarse"]["weights"][sb].data_ptr()
+                if use_fine:
+                    out.rgb_fine = res["fine"]["rgb"][sb].data_ptr()
+                    out.depth_fine = res["fine"]["depth"][sb].data_ptr()
+                    if want_weights:
+                        out.weights_fine = res["fine"]["weights"][sb].data_ptr()
+                for name, buf in extra.items():
+                    setattr(out, name, buf[sb].data_ptr())
+                if save:
+                    for name in ("z_coarse", "sample_coarse", "z_fine", "sample_fine"):
+                        if name in saved:
+                            setattr(out, name, saved[name][sb].data_ptr())
+                    saved["opts"].append(o)
+                    saved["keep"] = keep   # the explicit draws are read again by the backward (depth samples)
+                check(L.pny_render(model._scene(sb), ptr(rays[sb]), B, C.byref(o), C.byref(out), stream_of(dev)))
+        model.join_streams(streams)
         return res, saved
 
     def sched_step(self, steps=1):

@@ -391,3 +391,54 @@ def test_device_refresh_equals_full_reupload():
     net.invalidate_weights()
     fresh = net(xyz, coarse=True, viewdirs=vd)
     assert not torch.equal(stale, fresh)
+
+
+@pytest.mark.parametrize("streams", ["1", "0"])
+def test_render_backward_super_batch(streams, monkeypatch):
+    """SB = 3 scenes x B rays (the reference's training batch shape): the scenes' backward calls append to one
+    model-level stash (deferred weight gradients, side streams unless PNYOLO_SCENE_STREAMS=0) and one weight-gradient
+    GEMM per MLP sums over all of them; against the sum of the oracle's per-scene gradients."""
+    monkeypatch.setenv("PNYOLO_SCENE_STREAMS", streams)
+    SB, ns, H, W, kc, kf, kfd, n = 3, 2, 32, 32, 16, 8, 4, 24
+    c = pconf.default_mv()
+    net = make_model(c["model"], stop_encoder_grad=True)
+    sd_c, sd_f = synth.mlp_state(1401), synth.mlp_state(1402)
+    net.mlp_coarse.load_state_dict({k: torch.from_numpy(v) for k, v in sd_c.items()})
+    net.mlp_fine.load_state_dict({k: torch.from_numpy(v) for k, v in sd_f.items()})
+    net = net.to(DEV).train()
+    lat = np.concatenate([synth.latent(1410 + i, ns, 512, H // 2, W // 2) for i in range(SB)])
+    poses = np.stack([synth.scene_cameras(ns, radius=1.3 + 0.1 * i)[0] for i in range(SB)])
+    focal = torch.tensor([[28.0, 28.0], [30.0, 31.0], [27.0, 29.0]])
+    net.encode(torch.zeros(SB, ns, 3, H, W), torch.from_numpy(poses), focal, latent=torch.from_numpy(lat))
+    mc = {k: torch.from_numpy(v).requires_grad_() for k, v in sd_c.items()}
+    mf = {k: torch.from_numpy(v).requires_grad_() for k, v in sd_f.items()}
+    rs = np.random.RandomState(12)
+    rays_l, dr_l, scs = [], [], []
+    for i in range(SB):
+        sc = orc.Scene(mc, mf, lat[i * ns:(i + 1) * ns], poses[i], focal[i:i + 1], None, W, H)
+        sc.mlp_coarse, sc.mlp_fine = mc, mf
+        cand = orc.gen_rays(synth.pose_spherical(100.0 + 25 * i, -20.0, 1.3)[None], W, H, 29.0, 0.3, 1.8)[0].reshape(-1, 8)
+        nc = cand.shape[0]
+        dr = dict(u_coarse=rs.rand(nc, kc).astype(np.float32), u_fine=rs.rand(nc, kf - kfd).astype(np.float32),
+                  u_fine2=rs.rand(nc, kf - kfd).astype(np.float32), g_depth=rs.randn(nc, kfd).astype(np.float32))
+        keep = clean_rays(sc, cand, kc, kf, kfd, dr, n)
+        rays_l.append(cand[torch.from_numpy(keep)])
+        dr_l.append({k: v[keep] for k, v in dr.items()})
+        scs.append(sc)
+    rays = torch.stack(rays_l)
+    gt = torch.from_numpy(rs.uniform(0, 1, size=(SB, n, 3)).astype(np.float32))
+    ren = NeRFRenderer(n_coarse=kc, n_fine=kf, n_fine_depth=kfd, white_bkgd=True).train()
+    ren.draws = {k: np.concatenate([d[k] for d in dr_l]) for k in dr_l[0]}
+    out = ren(net, rays.to(DEV), want_weights=True)
+    loss = torch.nn.functional.mse_loss(out["coarse"]["rgb"], gt.to(DEV)) + torch.nn.functional.mse_loss(out["fine"]["rgb"], gt.to(DEV))
+    loss.backward()
+    ref_c, ref_f = [], []
+    for i in range(SB):
+        r = orc.render(scs[i], rays[i], kc, kf, kfd, dr_l[i]["u_coarse"], dr_l[i]["u_fine"], dr_l[i]["u_fine2"], dr_l[i]["g_depth"])
+        ref_c.append(r["coarse"]["rgb"])
+        ref_f.append(r["fine"]["rgb"])
+    ref_loss = torch.nn.functional.mse_loss(torch.stack(ref_c), gt) + torch.nn.functional.mse_loss(torch.stack(ref_f), gt)
+    assert abs(float(loss) - float(ref_loss)) < 1e-5
+    ref_loss.backward()
+    sc0 = scs[0]
+    compare_param_grads(net, sc0)
