@@ -291,6 +291,12 @@ typedef struct pny_render_grads {
 int pny_render_backward(pny_scene* s, const float* rays_dev, int64_t n, const pny_render_opts* opts,
                         const pny_render_saved* saved, const pny_render_grads* grads, int accumulate, pny_stream stream);
 
+/* Backward of pny_yolo_render (src/render/yolo.py:96-114 aggregation + the MLP; caller: train/trainlib/YoloTrainer.py:160-186):
+ * raw_dev (n, K, A*7) = the forward's raw_dev output, g_out_dev (n, A, 7) = dL/d(out); the sample depths are re-created
+ * from u_coarse_dev / seed as the forward made them.  Gradients go to the bound targets of mlp_coarse. */
+int pny_yolo_render_backward(pny_scene* s, const float* rays_dev, int64_t n, int n_coarse, const float* u_coarse_dev,
+                             uint64_t seed, const float* raw_dev, const float* g_out_dev, int accumulate, pny_stream stream);
+
 /* Deferred weight gradients.  A training batch holds several scenes (the reference's super-batch, SB objects x B rays,
  * train/train.py:23) whose backward calls are independent until the weight gradients are summed.  With deferral enabled
  * each pny_render_backward / pny_query_backward appends its tiles to a model-level stash (the calls of different scenes

@@ -682,4 +682,65 @@ void launch_depth_grad_gather(const int* sel, const float* dz, const float* g_in
     hipLaunchKernelGGL(depth_grad_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sel, dz, g_in, n, kfd, g_out);
 }
 
+// ---------------------------------------------------------------------------------------------- YOLO aggregation backward
+// Reverse of yolo_aggregate_kernel (render_kernels.hip; reference yolo.py:96-114): p_k = sigmoid(o0_k), P = sum_k p_k,
+//   out0 = max_k p_k,  out_i = sum_k p_k o_ik / (P + 1e-5), i = 1..6.
+//   dL/do_ik = g_i p_k / (P + eps);  dL/dp_k = [k == argmax] g_0 + sum_i g_i (o_ik - out_i) / (P + eps);  dL/do0_k = dL/dp_k p_k (1 - p_k)
+// One wavefront per (ray, anchor); the max's gradient goes to the first index that attains it (torch.max(dim)).
+__global__ __launch_bounds__(256) void yolo_aggregate_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ g,
+                                                                 long long n, int K, int na, float* __restrict__ d_raw) {
+    const int lane = threadIdx.x & 63;
+    const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= n * na) return;
+    const long long ray = item / na;
+    const int a = (int)(item - ray * na);
+    float ps = 0.f, pm = -1.f, v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int km = 0x7fffffff;
+    for (int k = lane; k < K; k += 64) {
+        const float* r = raw + ((ray * K + k) * na + a) * 7;
+        const float p = 1.0f / (1.0f + expf(-r[0]));
+        ps += p;
+        if (p > pm) {
+            pm = p;
+            km = k;
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) v[i] += r[1 + i] * p;
+    }
+    ps = bwd_wave_sum(ps);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[i] = bwd_wave_sum(v[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {   // (max, first index) reduction
+        const float pmo = __shfl_xor(pm, o, 64);
+        const int kmo = __shfl_xor(km, o, 64);
+        if (pmo > pm || (pmo == pm && kmo < km)) {
+            pm = pmo;
+            km = kmo;
+        }
+    }
+    const float den = ps + 1e-5f;
+    const float* gi = g + item * 7;
+    float gv[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) gv[i] = gi[i];
+    for (int k = lane; k < K; k += 64) {
+        const float* r = raw + ((ray * K + k) * na + a) * 7;
+        float* d = d_raw + ((ray * K + k) * na + a) * 7;
+        const float p = 1.0f / (1.0f + expf(-r[0]));
+        float dp = (k == km) ? gv[0] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            d[1 + i] = gv[1 + i] * (p / den);
+            dp += gv[1 + i] * ((r[1 + i] - v[i] / den) / den);
+        }
+        d[0] = dp * (p * (1.0f - p));
+    }
+}
+
+void launch_yolo_aggregate_bwd(const float* raw, const float* g, long long n, int k, int na, float* d_raw, hipStream_t st) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(yolo_aggregate_bwd_kernel, dim3((unsigned)((n * na + 3) / 4)), dim3(256), 0, st, raw, g, n, k, na, d_raw);
+}
+
 }  // namespace pny

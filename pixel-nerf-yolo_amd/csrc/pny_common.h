@@ -164,6 +164,7 @@ void launch_locate_depth_samples(const float* rays, const float* depth_c, const 
                                  long long n, int kt, int kfd, float depth_std, int* sel, hipStream_t st);
 void launch_mlp_dz(const DzArgs& a, hipStream_t st);
 void launch_depth_grad_gather(const int* sel, const float* dz, const float* g_in, long long n, int kfd, float* g_out, hipStream_t st);
+void launch_yolo_aggregate_bwd(const float* raw, const float* g, long long n, int k, int na, float* d_raw, hipStream_t st);
 void launch_mlp_bwd(const BwdArgs& a, int grid, hipStream_t st);
 void launch_dw_gemm(const DwJob* jobs_dev, const DwItem* items_dev, int n_items, const float* x_stash, const float* dy_stash,
                     long long x_tile, long long dy_tile, float* partial, float* bias_partial, hipStream_t st);

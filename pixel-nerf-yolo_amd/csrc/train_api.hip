@@ -503,6 +503,29 @@ int pny_render_backward(pny_scene* s, const float* rays_dev, int64_t n, const pn
     return PNY_OK;
 }
 
+int pny_yolo_render_backward(pny_scene* s, const float* rays_dev, int64_t n, int n_coarse, const float* u_coarse_dev, uint64_t seed,
+                             const float* raw_dev, const float* g_out_dev, int accumulate, pny_stream stream) {
+    int rc;
+    if ((rc = check_ready(s, "pny_yolo_render_backward"))) return rc;
+    const pny_model_desc& d = s->m->desc;
+    if (!d.yolo || d.d_out % 7) return fail(PNY_ERR_ARG, "pny_yolo_render_backward: model is not in YOLO mode");
+    if (n < 0 || n_coarse < 1 || (n > 0 && (!rays_dev || !raw_dev || !g_out_dev))) return fail(PNY_ERR_ARG, "pny_yolo_render_backward: bad argument");
+    if (n == 0) return PNY_OK;
+    PNY_HIP(hipSetDevice(d.device));
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = enter_stream(s, st))) return rc;
+    s->bev_used = 0;
+    s->bwd_flops[0] = s->bwd_flops[1] = s->bwd_flops[2] = 0.0;
+    const size_t nz = ((size_t)n * n_coarse + 63) & ~(size_t)63;
+    if ((rc = s->d_samp.reserve((size_t)n * n_coarse * d.d_out * sizeof(float)))) return rc;
+    if ((rc = s->dz_tmp.reserve(nz * sizeof(float)))) return rc;
+    float* z = s->dz_tmp.f();
+    launch_sample_coarse(rays_dev, n, n_coarse, 0, u_coarse_dev, seed, z, st);   // the forward's depths (same draws)
+    launch_yolo_aggregate_bwd(raw_dev, g_out_dev, n, n_coarse, d.d_out / 7, s->d_samp.f(), st);
+    PNY_HIP(hipGetLastError());
+    return mlp_backward(s, 1, nullptr, nullptr, rays_dev, z, n_coarse, (long long)n * n_coarse, 1, s->d_samp.f(), accumulate, st);
+}
+
 int pny_scene_last_backward_stats(pny_scene* s, double flops[3], double kernel_ms[3]) {
     if (!s) return fail(PNY_ERR_ARG, "pny_scene_last_backward_stats: null scene");
     for (int i = 0; i < 3; ++i) {

@@ -98,6 +98,8 @@ SIGNATURES = {
                                            C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pny_scene_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "pny_scene_last_backward_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "pny_yolo_render_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p,
+                                           C.c_void_p, C.c_int, C.c_void_p]),
     "pny_model_defer_weight_grads": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64]),
     "pny_model_flush_weight_grads": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "pny_model_last_flush_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -294,10 +294,17 @@ class YoloRenderer(torch.nn.Module):
 
     def forward(self, rays):
         """rays (..., 8) flattened to (N, 8) as the reference does (SB is folded away: only SB=1
-        is meaningful, yolo.py:38,81) -> (N, num_anchors_per_scale, 7)."""
+        is meaningful, yolo.py:38,81) -> (N, num_anchors_per_scale, 7).  Under autograd (trainable MLP parameters,
+        grad mode on) the result carries a graph: backward = pny_yolo_render_backward (YoloTrainer.py:160-186)."""
         net = self.net
-        if torch.is_grad_enabled() and (rays.requires_grad or net.training):
-            raise RuntimeError("libpnyolo is forward-only (SURVEY.md 8f): render in eval() mode or under no_grad()")
+        params = net.trainable_mlp_parameters() if torch.is_grad_enabled() else []
+        if params:
+            net.check_differentiable()
+            return _YoloRenderFunction.apply(self, rays, *[p for _, p in params])
+        return self._render(rays)[0]
+
+    def _render(self, rays, keep_raw=False):
+        net = self.net
         net._sync()
         L = _lib.load()
         dev = net._device()
@@ -312,16 +319,40 @@ class YoloRenderer(torch.nn.Module):
         if draws is not None:
             u = torch.as_tensor(draws["u_coarse"], dtype=torch.float32).reshape(n, self.n_coarse).to(dev).contiguous()
         raw = getattr(self, "_debug_raw", None)
-        check(L.pny_yolo_render(net._scene(0), ptr(rays), n, int(self.n_coarse), ptr(u),
-                                (self.base_seed + 7919 * self._calls) & 0xFFFFFFFFFFFFFFFF, ptr(out), ptr(raw),
+        if raw is None and keep_raw:
+            raw = torch.empty(n, int(self.n_coarse), net.d_out, device=dev, dtype=torch.float32)
+        seed = (self.base_seed + 7919 * self._calls) & 0xFFFFFFFFFFFFFFFF
+        check(L.pny_yolo_render(net._scene(0), ptr(rays), n, int(self.n_coarse), ptr(u), seed, ptr(out), ptr(raw),
                                 stream_of(dev)))
-        return out
+        return out, dict(rays=rays, u=u, seed=seed, raw=raw, n_coarse=int(self.n_coarse))
 
     def bind_parallel(self, net, gpus=None):
         self.net = net
         if gpus is not None and len(gpus) > 1:
             raise NotImplementedError("multi-GPU: one process per GPU (pixel_nerf_yolo_amd.dist), not DataParallel")
         return self
+
+
+class _YoloRenderFunction(torch.autograd.Function):
+    """YoloRenderer.forward under autograd: pny_yolo_render forward (raw per-sample vectors kept),
+    pny_yolo_render_backward into gradient buffers bound to the parameters of mlp_coarse."""
+
+    @staticmethod
+    def forward(ctx, renderer, rays, *params):
+        out, saved = renderer._render(rays, keep_raw=True)
+        ctx.renderer, ctx.saved = renderer, saved
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        net, sv = ctx.renderer.net, ctx.saved
+        L = _lib.load()
+        dev = net._device()
+        grads = net.bind_mlp_grads()
+        g_out = g_out.detach().to(dev, torch.float32).contiguous()
+        check(L.pny_yolo_render_backward(net._scene(0), ptr(sv["rays"]), sv["rays"].shape[0], sv["n_coarse"], ptr(sv["u"]),
+                                         sv["seed"], ptr(sv["raw"]), ptr(g_out), 1, stream_of(dev)))
+        return (None, None) + tuple(grads)
 
 
 def make_renderer(conf, lindisp=False):

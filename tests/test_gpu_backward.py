@@ -442,3 +442,38 @@ def test_render_backward_super_batch(streams, monkeypatch):
     ref_loss.backward()
     sc0 = scs[0]
     compare_param_grads(net, sc0)
+
+
+def test_yolo_render_backward_vs_oracle():
+    """YoloRenderer under autograd (the fork's own training path, YoloTrainer.py:160-186): probability-weighted
+    aggregation along the ray (yolo.py:96-114) + raw 21-vector MLP, L = 1792, against autograd through the oracle."""
+    from pixel_nerf_yolo_amd.render import YoloRenderer
+    n, K = 40, 32
+    net, sc = scene_pair(2, 64, 64, 1792, 21, 5, 3, 1500, yolo=True, lat_hw=(8, 8))
+    _, tgt_c2w = synth.scene_cameras(2, radius=4.0, phi=-25.0)
+    flipyz = np.diag([1.0, -1.0, -1.0, 1.0]).astype(np.float32)
+    tgt_w2c = np.linalg.inv(tgt_c2w @ flipyz).astype(np.float32)
+    cand = orc.gen_rays_yolo(tgt_w2c[None], 16, 12, [5.0, 5.5], [8.0, 6.0], 1.0, 6.0)[0].reshape(-1, 8)
+    rs = np.random.RandomState(21)
+    u_all = rs.rand(cand.shape[0], K).astype(np.float32)
+    orc.RELU_TRACE = []
+    with torch.no_grad():
+        orc.yolo_render(sc, cand, K, u_all)
+    ok = torch.ones(cand.shape[0], dtype=torch.bool)
+    for t in orc.RELU_TRACE:
+        ok &= t.reshape(cand.shape[0], -1).min(dim=1)[0] >= AMBIG
+    orc.RELU_TRACE = None
+    keep = ok.nonzero().flatten()[:n]
+    assert keep.numel() == n, int(ok.sum())
+    rays, u = cand[keep], u_all[keep.numpy()]
+    G = torch.from_numpy(rs.standard_normal((n, 3, 7)).astype(np.float32))
+    ren = YoloRenderer(K, 128, 1, 3)
+    ren.bind_parallel(net)
+    ren.draws = dict(u_coarse=u)
+    out = ren(rays[None].to(DEV))
+    assert out.requires_grad and out.shape == (n, 3, 7)
+    (out * G.to(DEV)).sum().backward()
+    ref = orc.yolo_render(sc, rays, K, u)
+    assert maxabs(out, ref["out"].detach()) < 1e-4 * max(1.0, float(ref["out"].detach().abs().max()))
+    (ref["out"] * G).sum().backward()
+    compare_param_grads(net, sc, which=("mlp_coarse",))
