@@ -306,6 +306,12 @@ int pny_yolo_render_backward(pny_scene* s, const float* rays_dev, int64_t n, int
  * PNY_ERR_ARG when the reservation exceeds the stash budget (the caller then stays in immediate mode).  The flush must be
  * ordered after the scenes' calls by the caller (same stream, or events). */
 int pny_model_defer_weight_grads(pny_model* m, int enable, int ns, int64_t coarse_tiles, int64_t fine_tiles);
+/* Stash in the forward.  With a reservation in place, enable = 1 makes the NEXT pny_render on this scene evaluate both
+ * MLP passes with the stashing instantiation (reference operation order; rgb / sigma within fp32 rounding of the
+ * projected evaluation) directly into the reservation; the pny_render_backward that follows (same reservation, z_* /
+ * sample_* of that forward given in pny_render_saved) then skips its forward recompute and starts at the dX chain.
+ * One-shot: the flag clears itself; a pass that does not fit the reservation runs the plain forward. */
+int pny_scene_stash_next_render(pny_scene* s, int enable);
 int pny_model_flush_weight_grads(pny_model* m, int accumulate, pny_stream stream);
 /* GEMM FLOPs and HIP-event time of the last flush. */
 int pny_model_last_flush_stats(pny_model* m, double* flops, double* kernel_ms);

@@ -699,13 +699,54 @@ int fill_mlp_args(pny_scene* s, int mode, const float* xyz, const float* dirs, c
 }  // namespace pny
 
 static int run_mlp(pny_scene* s, int mode, const float* xyz, const float* dirs, const float* rays, const float* z,
-                   int K, long long n_points, int coarse, float* out, hipStream_t st) {
+                   int K, long long n_points, int coarse, float* out, hipStream_t st, int stash_pass = -1) {
     if (n_points == 0) return 0;
     const pny_model_desc& d = s->m->desc;
     MlpArgs a;
     int rc;
     if ((rc = fill_mlp_args(s, mode, xyz, dirs, rays, z, K, n_points, coarse, out, &a))) return rc;
     const bool fine_w = !(coarse || !d.has_fine || !s->m->use_fine);
+    if (stash_pass >= 0) {
+        // Training forward (pny_scene_stash_next_render): the STASH instantiation (reference operation order, 64-sample
+        // tiles) writes every GEMM operand into the tiles this pass takes from the model-level reservation; the backward
+        // of the same reservation epoch then starts at the dX chain.
+        pny_model* m = s->m;
+        const int which = fine_w ? 1 : 0;
+        pny_scene::StashedPass& sp = s->stashed[stash_pass];
+        sp.valid = false;
+        if (m->defer && s->ns == m->defer_ns && m->defer_used[which] + a.n_tiles <= m->defer_cap[which]) {
+            a.lay = stash_layout(d, s->ns, s->L);
+            a.stash_x = m->dx_stash[which].f() + m->defer_used[which] * a.lay.x_tile;
+            sp.valid = true;
+            sp.epoch = m->defer_epoch;
+            sp.which = which;
+            sp.tile0 = m->defer_used[which];
+            sp.tiles = a.n_tiles;
+            sp.n_points = n_points;
+            m->defer_used[which] += a.n_tiles;
+            const int grid = std::min(mlp_max_grid(MLP_8x64), a.n_tiles);
+            if (s->timing) {
+                while ((int)s->ev.size() < s->ev_used + 2) {
+                    hipEvent_t e;
+                    PNY_HIP(hipEventCreate(&e));
+                    s->ev.push_back(e);
+                }
+                PNY_HIP(hipEventRecord(s->ev[s->ev_used], st));
+            }
+            launch_mlp_stash(a, grid, st);
+            PNY_HIP(hipGetLastError());
+            if (s->timing) {
+                PNY_HIP(hipEventRecord(s->ev[s->ev_used + 1], st));
+                s->ev_used += 2;
+            }
+            s->last_flops += mlp_flops_per_point(d, s->ns, true) * (double)n_points;
+            s->last_flops_ref += mlp_flops_per_point(d, s->ns, true) * (double)n_points;
+            s->last_projected = false;
+            s->last_launches += 1;
+            return 0;
+        }
+        // no room in the reservation: plain forward, the backward recomputes
+    }
     if ((rc = ensure_projection(s, fine_w ? 1 : 0, n_points, st, &a.zp))) return rc;
     a.tap_stride = a.zp ? a.zp_stride : s->L;
     const int variant = mlp_pick_variant(n_points);
@@ -838,8 +879,11 @@ int pny_render(pny_scene* s, const float* rays_dev, int64_t n, const pny_render_
     float* dc = out->depth_coarse ? out->depth_coarse : W + o_dc;
     float* rgbc = out->rgb_coarse ? out->rgb_coarse : W + o_rc;
 
+    const bool stash = s->stash_next;
+    s->stash_next = false;
+    s->stashed[0].valid = s->stashed[1].valid = false;
     launch_sample_coarse(rays_dev, n, kc, o->lindisp, o->u_coarse_dev, o->seed, zc, st);
-    if ((rc = run_mlp(s, 1, nullptr, nullptr, rays_dev, zc, kc, (long long)n * kc, 1, sc, st))) return rc;
+    if ((rc = run_mlp(s, 1, nullptr, nullptr, rays_dev, zc, kc, (long long)n * kc, 1, sc, st, stash ? 0 : -1))) return rc;
     launch_composite(rays_dev, zc, sc, n, kc, o->white_bkgd, wc, rgbc, dc, st);
     if (o->n_fine > 0) {
         float* zf = out->z_fine ? out->z_fine : W + o_zf;
@@ -848,7 +892,7 @@ int pny_render(pny_scene* s, const float* rays_dev, int64_t n, const pny_render_
             return fail(PNY_ERR_ARG, "pny_render: n_coarse + n_fine too large for the LDS-resident sort");
         launch_sample_fine(rays_dev, zc, wc, dc, n, kc, o->n_fine, o->n_fine_depth, o->depth_std, o->lindisp,
                            o->u_fine_dev, o->u_fine2_dev, o->g_depth_dev, o->seed, zf, st);
-        if ((rc = run_mlp(s, 1, nullptr, nullptr, rays_dev, zf, kt, (long long)n * kt, 0, sf, st))) return rc;
+        if ((rc = run_mlp(s, 1, nullptr, nullptr, rays_dev, zf, kt, (long long)n * kt, 0, sf, st, stash ? 1 : -1))) return rc;
         launch_composite(rays_dev, zf, sf, n, kt, o->white_bkgd, out->weights_fine, out->rgb_fine, out->depth_fine, st);
     }
     PNY_HIP(hipGetLastError());

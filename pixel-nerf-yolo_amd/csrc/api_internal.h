@@ -128,6 +128,7 @@ struct pny_model {
     DevBuf dx_stash[2], ddy_stash[2], d_partial[2], d_bias[2], d_tables[2];
     PinnedStage d_stage[2];
     long long defer_cap[2] = {0, 0}, defer_used[2] = {0, 0};
+    uint64_t defer_epoch = 0;                // bumped by every pny_model_defer_weight_grads(enable)
     hipEvent_t flush_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     double flush_flops = 0.0;
     int flush_launches = 0;
@@ -165,6 +166,15 @@ struct pny_scene {
     // training workspace (train_api.hip)
     DevBuf x_stash, dy_stash, dw_partial, dw_bias, dw_tables, d_samp, out_tmp, dz_tmp, sel_tmp, gdepth_tmp;
     PinnedStage table_stage;
+    // "stash in the forward": the next pny_render evaluates the MLPs with the STASH instantiation straight into the
+    // model-level stash (deferred mode); what each pass wrote is remembered for the backward of the same epoch
+    bool stash_next = false;
+    struct StashedPass {
+        bool valid = false;
+        uint64_t epoch = 0;
+        int which = 0;
+        long long tile0 = 0, tiles = 0, n_points = 0;
+    } stashed[2];   // [0] coarse pass, [1] fine pass
     // HIP-event timing of the backward kernels of the last backward call (enable_timing): per MLP pass 4 events
     std::vector<hipEvent_t> bev;
     int bev_used = 0;
@@ -179,6 +189,7 @@ namespace pny {
 int enter_stream(pny_scene* s, hipStream_t st);
 int check_ready(pny_scene* s, const char* who);
 int view_blocks(const pny_model_desc& d);
+StashLayout stash_layout(const pny_model_desc& d, int ns, int L);
 // projected latent maps of the coarse (0) / fine (1) MLP, computed if stale; force = regardless of the scene's mode
 int ensure_projection(pny_scene* s, int which, long long n_points, hipStream_t st, const float** zp, bool force = false);
 // MlpArgs of a launch on this scene in the reference's operation order (no projected latent); tiles of 64 samples

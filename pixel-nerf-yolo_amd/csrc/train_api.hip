@@ -11,6 +11,23 @@
 
 using namespace pny;
 
+namespace pny {
+StashLayout stash_layout(const pny_model_desc& d, int ns, int L) {
+    const int nb = d.n_blocks, nvb = view_blocks(d), npost = nb - nvb;
+    StashLayout l;
+    l.x_in = 0;
+    l.x_z = STASH_SMALL;
+    l.x_act = STASH_SMALL + L * 64;
+    l.x_view = l.x_act + 2 * nvb * STASH_SLOT;
+    l.x_post = ns * l.x_view;
+    l.x_tile = (long long)l.x_post + (long long)(2 * npost + 1) * STASH_SLOT;
+    l.dy_view = 2 * nvb * STASH_SLOT;
+    l.dy_post = ns * l.dy_view;
+    l.dy_tile = (long long)l.dy_post + STASH_SMALL + (long long)(1 + 2 * npost) * STASH_SLOT;
+    return l;
+}
+}  // namespace pny
+
 namespace {
 
 struct TrainPlan {
@@ -30,16 +47,8 @@ TrainPlan build_plan(const pny_model* m, int ns, int L, const std::string& pre) 
     const int nb = d.n_blocks, nvb = view_blocks(d), npost = nb - nvb;
     const int d_in = 3 + 6 * d.num_freqs + 3;
     TrainPlan p;
+    p.lay = stash_layout(d, ns, L);
     StashLayout& l = p.lay;
-    l.x_in = 0;
-    l.x_z = STASH_SMALL;
-    l.x_act = STASH_SMALL + L * 64;
-    l.x_view = l.x_act + 2 * nvb * STASH_SLOT;
-    l.x_post = ns * l.x_view;
-    l.x_tile = (long long)l.x_post + (long long)(2 * npost + 1) * STASH_SLOT;
-    l.dy_view = 2 * nvb * STASH_SLOT;
-    l.dy_post = ns * l.dy_view;
-    l.dy_tile = (long long)l.dy_post + STASH_SMALL + (long long)(1 + 2 * npost) * STASH_SLOT;
     auto xact = [&](int i) { return (long long)l.x_act + (long long)i * STASH_SLOT; };
     auto xpost = [&](int i) { return (long long)l.x_post + (long long)i * STASH_SLOT; };
     auto dyv = [&](int i) { return (long long)i * STASH_SLOT; };
@@ -138,13 +147,10 @@ void build_items(TrainPlan& p, int n_tiles, int cus, std::vector<DwItem>& items,
 }
 
 size_t stash_budget_bytes() {
-    static size_t v = 0;
-    if (!v) {
-        v = (size_t)16 << 30;  // both stashes together; PNYOLO_STASH_GB overrides
-        if (const char* e = getenv("PNYOLO_STASH_GB")) {
-            const double g = atof(e);
-            if (g > 0.01) v = (size_t)(g * (double)((size_t)1 << 30));
-        }
+    size_t v = (size_t)16 << 30;  // both stashes together; PNYOLO_STASH_GB overrides (read at every call: tests vary it)
+    if (const char* e = getenv("PNYOLO_STASH_GB")) {
+        const double g = atof(e);
+        if (g > 0.001) v = (size_t)(g * (double)((size_t)1 << 30));
     }
     return v;
 }
@@ -190,9 +196,14 @@ int run_weight_grads(TrainPlan& plan, int n_tiles, const float* x_stash, const f
 // through the MLP inputs is added to dz_out (n_points).
 int mlp_backward(pny_scene* s, int mode, const float* xyz, const float* dirs, const float* rays, const float* z, int K,
                  long long n_points, int coarse, const float* d_out, int accumulate, hipStream_t st,
-                 const int* dz_sel = nullptr, int kfd = 0, float* dz_out = nullptr) {
+                 const int* dz_sel = nullptr, int kfd = 0, float* dz_out = nullptr,
+                 const pny_scene::StashedPass* stashed = nullptr, const float* fwd_out = nullptr, bool immediate = false) {
     if (n_points == 0) return 0;
     pny_model* m = s->m;
+    // forward already stashed by pny_render (same reservation epoch): no recompute, the tiles are in the model-level stash
+    const bool have_x = !immediate && stashed && stashed->valid && m->defer && stashed->epoch == m->defer_epoch &&
+                        stashed->n_points == n_points && fwd_out;
+    const bool defer = m->defer && !immediate;
     const pny_model_desc& d = m->desc;
     const bool fine_w = !(coarse || !d.has_fine || !m->use_fine);
     const std::string pre = fine_w ? "mlp_fine." : "mlp_coarse.";
@@ -212,7 +223,11 @@ int mlp_backward(pny_scene* s, int mode, const float* xyz, const float* dirs, co
     const int which = fine_w ? 1 : 0;
     float* x_base = nullptr;
     float* dy_base = nullptr;
-    if (m->defer) {
+    if (have_x) {
+        chunk_pts = n_points;
+        x_base = m->dx_stash[stashed->which].f() + stashed->tile0 * plan.lay.x_tile;
+        dy_base = m->ddy_stash[stashed->which].f() + stashed->tile0 * plan.lay.dy_tile;
+    } else if (defer) {
         const long long tiles = (n_points + 63) / 64;
         if (s->ns != m->defer_ns) return fail(PNY_ERR_STATE, "deferred weight gradients: scene view count differs from the reservation");
         if (m->defer_used[which] + tiles > m->defer_cap[which])
@@ -244,7 +259,7 @@ int mlp_backward(pny_scene* s, int mode, const float* xyz, const float* dirs, co
         const double post_f = 2.0 * npost_ * HID * HID + (double)HID * d.d_out;
         const double fwd = 2.0 * (s->ns * per_view_f + post_f);
         const double chain = 2.0 * (s->ns * 2.0 * nvb_ * HID * HID + 2.0 * npost_ * HID * HID + (double)HID * d.d_out);
-        s->bwd_flops[0] += fwd * (double)n_points;
+        if (!have_x) s->bwd_flops[0] += fwd * (double)n_points;   // the forward already stashed: nothing is recomputed
         s->bwd_flops[1] += chain * (double)n_points;
         s->bwd_flops[2] += fwd * (double)n_points;   // every forward GEMM has one weight-gradient GEMM of the same size
     }
@@ -266,8 +281,10 @@ int mlp_backward(pny_scene* s, int mode, const float* xyz, const float* dirs, co
         a.lay = plan.lay;
         const int grid = std::min(cus, n_tiles);
         if ((rc = stamp())) return rc;
-        launch_mlp_stash(a, grid, st);
-        PNY_HIP(hipGetLastError());
+        if (!have_x) {
+            launch_mlp_stash(a, grid, st);
+            PNY_HIP(hipGetLastError());
+        }
         if ((rc = stamp())) return rc;
         // 2. dX chain
         const MlpWeightsT& wt = fine_w ? m->fine_t : m->coarse_t;
@@ -283,7 +300,7 @@ int mlp_backward(pny_scene* s, int mode, const float* xyz, const float* dirs, co
         b.x_stash = x_base;
         b.dy_stash = dy_base;
         b.lay = plan.lay;
-        b.out = s->out_tmp.f();
+        b.out = have_x ? fwd_out : s->out_tmp.f();
         b.d_out_grad = d_out + p0 * d.d_out;
         b.n_points = np;
         b.n_tiles = n_tiles;
@@ -327,7 +344,7 @@ int mlp_backward(pny_scene* s, int mode, const float* xyz, const float* dirs, co
             PNY_HIP(hipGetLastError());
         }
         // 3. weight-gradient GEMMs over the two stashes + deterministic split reduction into the bound gradients
-        if (!m->defer &&
+        if (!defer && !have_x &&
             (rc = run_weight_grads(plan, n_tiles, x_base, dy_base, s->dw_partial, s->dw_bias, s->dw_tables, s->table_stage,
                                    (accumulate || p0 > 0) ? 1 : 0, st)))
             return rc;
@@ -353,6 +370,7 @@ int pny_model_defer_weight_grads(pny_model* m, int enable, int ns, int64_t coars
     if (!m) return fail(PNY_ERR_ARG, "pny_model_defer_weight_grads: null model");
     m->defer = false;
     m->defer_used[0] = m->defer_used[1] = 0;
+    ++m->defer_epoch;   // passes stashed under the previous reservation are no longer valid
     if (!enable) return PNY_OK;
     if (ns < 1 || ns > MAX_VIEWS || coarse_tiles < 0 || fine_tiles < 0) return fail(PNY_ERR_ARG, "pny_model_defer_weight_grads: bad argument");
     PNY_HIP(hipSetDevice(m->desc.device));
@@ -369,6 +387,7 @@ int pny_model_defer_weight_grads(pny_model* m, int enable, int ns, int64_t coars
     }
     m->defer_ns = ns;
     m->defer = true;
+    ++m->defer_epoch;
     return PNY_OK;
 }
 
@@ -417,6 +436,13 @@ int pny_model_last_flush_stats(pny_model* m, double* flops, double* kernel_ms) {
     return PNY_OK;
 }
 
+int pny_scene_stash_next_render(pny_scene* s, int enable) {
+    if (!s) return fail(PNY_ERR_ARG, "pny_scene_stash_next_render: null scene");
+    if (enable && !s->m->defer) return fail(PNY_ERR_STATE, "pny_scene_stash_next_render: reserve the stash first (pny_model_defer_weight_grads)");
+    s->stash_next = enable != 0;
+    return PNY_OK;
+}
+
 int pny_query_backward(pny_scene* s, const float* xyz_dev, const float* viewdirs_dev, int64_t n, int coarse,
                        const float* d_out_dev, int accumulate, pny_stream stream) {
     int rc;
@@ -459,6 +485,7 @@ int pny_render_backward(pny_scene* s, const float* rays_dev, int64_t n, const pn
     s->bwd_flops[0] = s->bwd_flops[1] = s->bwd_flops[2] = 0.0;
     if ((rc = s->d_samp.reserve((size_t)n * kt * 4 * sizeof(float)))) return rc;
     const bool same_mlp = !s->m->desc.has_fine || !s->m->use_fine;  // both passes differentiate mlp_coarse
+    const bool immediate = (accumulate & 2) != 0;   // ignore a deferred reservation that belongs to another forward
     bool first = true;
     const bool any_f = o->n_fine > 0 && (g->rgb_fine || g->depth_fine || g->weights_fine);
     const bool any_c = g->rgb_coarse || g->depth_coarse || g->weights_coarse;
@@ -467,6 +494,17 @@ int pny_render_backward(pny_scene* s, const float* rays_dev, int64_t n, const pn
     // part; summed over a ray's unclamped depth samples it is an extra dL/d(depth_coarse).
     const int kfd = o->n_fine_depth;
     const bool depth_path = any_f && kfd > 0 && sv->depth_coarse;
+    {   // a pass that was stashed by the forward but receives no gradient must not leave stale dY tiles for the flush
+        pny_model* m = s->m;
+        const long long dy_tile = stash_layout(m->desc, s->ns, s->L).dy_tile;
+        auto zero_pass = [&](const pny_scene::StashedPass& sp) -> int {
+            if (sp.valid && m->defer && !immediate && sp.epoch == m->defer_epoch)
+                PNY_HIP(hipMemsetAsync(m->ddy_stash[sp.which].f() + sp.tile0 * dy_tile, 0, (size_t)sp.tiles * dy_tile * sizeof(float), st));
+            return 0;
+        };
+        if (!any_f && (rc = zero_pass(s->stashed[1]))) return rc;
+        if (!(any_c || depth_path) && (rc = zero_pass(s->stashed[0]))) return rc;
+    }
     const float* g_depth_c = g->depth_coarse;
     if (any_f) {
         float* dz = nullptr;
@@ -482,8 +520,8 @@ int pny_render_backward(pny_scene* s, const float* rays_dev, int64_t n, const pn
         launch_composite_bwd(rays_dev, sv->z_fine, sv->sample_fine, nullptr, n, kt, o->white_bkgd, g->rgb_fine, g->depth_fine,
                              g->weights_fine, s->d_samp.f(), dz, st);
         PNY_HIP(hipGetLastError());
-        if ((rc = mlp_backward(s, 1, nullptr, nullptr, rays_dev, sv->z_fine, kt, (long long)n * kt, 0, s->d_samp.f(), accumulate, st,
-                               sel, kfd, dz)))
+        if ((rc = mlp_backward(s, 1, nullptr, nullptr, rays_dev, sv->z_fine, kt, (long long)n * kt, 0, s->d_samp.f(), accumulate & 1, st,
+                               sel, kfd, dz, &s->stashed[1], sv->sample_fine, immediate)))
             return rc;
         if (depth_path) {
             launch_depth_grad_gather(sel, dz, g->depth_coarse, n, kfd, s->gdepth_tmp.f(), st);
@@ -497,7 +535,8 @@ int pny_render_backward(pny_scene* s, const float* rays_dev, int64_t n, const pn
                              g->weights_coarse, s->d_samp.f(), nullptr, st);
         PNY_HIP(hipGetLastError());
         if ((rc = mlp_backward(s, 1, nullptr, nullptr, rays_dev, sv->z_coarse, kc, (long long)n * kc, 1, s->d_samp.f(),
-                               (accumulate || (same_mlp && !first)) ? 1 : 0, st)))
+                               ((accumulate & 1) || (same_mlp && !first)) ? 1 : 0, st, nullptr, 0, nullptr, &s->stashed[0],
+                               sv->sample_coarse, immediate)))
             return rc;
     }
     return PNY_OK;

@@ -101,6 +101,7 @@ SIGNATURES = {
     "pny_yolo_render_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p,
                                            C.c_void_p, C.c_int, C.c_void_p]),
     "pny_model_defer_weight_grads": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64]),
+    "pny_scene_stash_next_render": (C.c_int, [C.c_void_p, C.c_int]),
     "pny_model_flush_weight_grads": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "pny_model_last_flush_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "pny_model_bind_grad": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p]),

@@ -542,7 +542,9 @@ class PixelNeRFNet(nn.Module):
         """
         if torch.is_grad_enabled() and xyz.requires_grad:
             raise RuntimeError("libpnyolo does not differentiate w.r.t. the query points: detach xyz")
-        if torch.is_grad_enabled() and self.trainable_mlp_parameters():
+        # autograd path in train() mode only: eval-mode calls outside no_grad (the reference's eval scripts are not
+        # consistent about it) return plain tensors, as before
+        if torch.is_grad_enabled() and self.training and self.trainable_mlp_parameters():
             self.check_differentiable()
             return _QueryFunction.apply(self, xyz, bool(coarse), viewdirs, *[p for _, p in self.trainable_mlp_parameters()])
         return self._query(xyz, coarse, viewdirs)

@@ -47,7 +47,23 @@ class _RenderFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, renderer, model, rays, has_fine, n_params, *params):
-        res, saved = renderer._render(model, rays, want_weights=True, save=True)
+        # Reserve the model-level stash for every scene's tiles (pny_model_defer_weight_grads): the forward then writes the
+        # GEMM operands the backward needs while it evaluates the MLPs (no recompute), the scenes' backward calls run on
+        # side streams and ONE weight-gradient GEMM per MLP follows.  If the reservation exceeds the stash budget: plain
+        # forward, scene-after-scene backward with recompute in chunks.
+        model._sync()
+        L = _lib.load()
+        SB, B = rays.shape[0], rays.shape[1]
+        kc = int(renderer.n_coarse)
+        kt = kc + int(renderer.n_fine) if has_fine else 0
+        tiles = lambda pts: -(-pts // 64)
+        fine_mlp = model.mlp_fine is not None
+        ct = tiles(B * kc) + (tiles(B * kt) if (has_fine and not fine_mlp) else 0)
+        ft = tiles(B * kt) if (has_fine and fine_mlp) else 0
+        ctx.deferred = L.pny_model_defer_weight_grads(model._h_model, 1, model.num_views_per_obj, SB * ct, SB * ft) == 0
+        model._defer_token = getattr(model, "_defer_token", 0) + 1
+        ctx.token = model._defer_token
+        res, saved = renderer._render(model, rays, want_weights=True, save=True, stash=ctx.deferred)
         saved["depth_coarse"] = res["coarse"]["depth"]
         ctx.renderer, ctx.model, ctx.saved, ctx.has_fine = renderer, model, saved, has_fine
         ctx.white_bkgd = bool(renderer.white_bkgd)
@@ -75,14 +91,10 @@ class _RenderFunction(torch.autograd.Function):
             return t.detach().to(dev, torch.float32).contiguous()
 
         ups = [prep(x) for x in (g_rgb_c, g_depth_c, g_w_c, g_rgb_f, g_depth_f, g_w_f)]
-        # Scenes of a super-batch are independent until their weight gradients are summed: with the tiles of all scenes
-        # in one model-level stash (pny_model_defer_weight_grads) the per-scene calls run on side streams and ONE
-        # weight-gradient GEMM per MLP follows; if the reservation does not fit the stash budget, scene after scene.
-        tiles = lambda pts: -(-pts // 64)
-        fine_mlp = model.mlp_fine is not None
-        ct = tiles(B * kc) + (tiles(B * kt) if (ctx.has_fine and not fine_mlp) else 0)
-        ft = tiles(B * kt) if (ctx.has_fine and fine_mlp) else 0
-        deferred = SB > 1 and L.pny_model_defer_weight_grads(model._h_model, 1, model.num_views_per_obj, SB * ct, SB * ft) == 0
+        # The reservation made by the forward is still ours unless another training forward ran in between: then this
+        # call computes its weight gradients immediately (accumulate bit 1), scene after scene, with recompute.
+        deferred = ctx.deferred and getattr(model, "_defer_token", None) == ctx.token
+        acc = 1 if deferred else 3
         streams = model.fork_streams(SB) if deferred else [None] * SB
         for sb in range(SB):
             with torch.cuda.stream(streams[sb]):
@@ -94,7 +106,7 @@ class _RenderFunction(torch.autograd.Function):
                     s_.sample_fine = sv["sample_fine"][sb].data_ptr()
                 gr = _lib.RenderGrads(*[None if p is None else p[sb].data_ptr() for p in ups])
                 check(L.pny_render_backward(model._scene(sb), ptr(sv["rays"][sb]), B, C.byref(sv["opts"][sb]), C.byref(s_),
-                                            C.byref(gr), 1, stream_of(dev)))
+                                            C.byref(gr), acc, stream_of(dev)))
         if deferred:
             model.join_streams(streams)
             check(L.pny_model_flush_weight_grads(model._h_model, 1, stream_of(dev)))
@@ -132,7 +144,7 @@ class NeRFRenderer(torch.nn.Module):
         :return dict(coarse=dict(rgb (SB,B,3), depth (SB,B)[, weights (SB,B,Kc)]), fine=dict(...))
         ``fine`` is absent when n_fine == 0 (callers test ``len(fine) > 0``, PixelNerfTrainer.py:140-143).
 
-        Under autograd (grad mode on and MLP parameters that require grad) the call goes through ``_RenderFunction``:
+        Under autograd (grad mode on, ``model.train()`` and MLP parameters that require grad) the call goes through ``_RenderFunction``:
         same forward kernels, and ``loss.backward()`` fills ``.grad`` of the MLP parameters through
         pny_render_backward (include/pnyolo.h).  The encoder is not differentiated: it must be frozen
         (``stop_encoder_grad`` / ``--freeze_enc`` of the reference, train/train.py:70-73)."""
@@ -142,7 +154,7 @@ class NeRFRenderer(torch.nn.Module):
         assert len(rays.shape) == 3
         if self.training and self.noise_std > 0.0:
             raise NotImplementedError("sigma noise (noise_std > 0, training only) is not implemented")
-        params = model.trainable_mlp_parameters() if torch.is_grad_enabled() else []
+        params = model.trainable_mlp_parameters() if (torch.is_grad_enabled() and model.training) else []
         if not params:
             res, _ = self._render(model, rays, want_weights, save=False)
             return res
@@ -158,7 +170,7 @@ class NeRFRenderer(torch.nn.Module):
                 res["fine"]["weights"] = outs[5]
         return res
 
-    def _render(self, model, rays, want_weights, save):
+    def _render(self, model, rays, want_weights, save, stash=False):
         """One pny_render call per scene.  save=True also returns what the backward needs: the detached device rays,
         the sample depths and the per-sample MLP outputs of both passes, and the options of every scene's call."""
         model._sync()
@@ -230,6 +242,8 @@ class NeRFRenderer(torch.nn.Module):
                             setattr(out, name, saved[name][sb].data_ptr())
                     saved["opts"].append(o)
                     saved["keep"] = keep   # the explicit draws are read again by the backward (depth samples)
+                if stash:   # training forward into the reserved stash (pny_scene_stash_next_render)
+                    check(L.pny_scene_stash_next_render(model._scene(sb), 1))
                 check(L.pny_render(model._scene(sb), ptr(rays[sb]), B, C.byref(o), C.byref(out), stream_of(dev)))
         model.join_streams(streams)
         return res, saved
@@ -297,7 +311,7 @@ class YoloRenderer(torch.nn.Module):
         is meaningful, yolo.py:38,81) -> (N, num_anchors_per_scale, 7).  Under autograd (trainable MLP parameters,
         grad mode on) the result carries a graph: backward = pny_yolo_render_backward (YoloTrainer.py:160-186)."""
         net = self.net
-        params = net.trainable_mlp_parameters() if torch.is_grad_enabled() else []
+        params = net.trainable_mlp_parameters() if (torch.is_grad_enabled() and net.training) else []
         if params:
             net.check_differentiable()
             return _YoloRenderFunction.apply(self, rays, *[p for _, p in params])

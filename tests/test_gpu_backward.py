@@ -477,3 +477,60 @@ def test_yolo_render_backward_vs_oracle():
     assert maxabs(out, ref["out"].detach()) < 1e-4 * max(1.0, float(ref["out"].detach().abs().max()))
     (ref["out"] * G).sum().backward()
     compare_param_grads(net, sc, which=("mlp_coarse",))
+
+
+def _batch_for(net_seed, n, kc=16, kf=8, kfd=4, H=32, W=32, ns=2):
+    net, sc = scene_pair(ns, H, W, 512, 4, 5, 3, net_seed)
+    _, tgt = synth.scene_cameras(ns)
+    rs = np.random.RandomState(net_seed)
+    nc = H * W
+    cand = orc.gen_rays(tgt[None], W, H, 0.9 * W, 0.3, 1.8)[0].reshape(-1, 8)
+    dr = dict(u_coarse=rs.rand(nc, kc).astype(np.float32), u_fine=rs.rand(nc, kf - kfd).astype(np.float32),
+              u_fine2=rs.rand(nc, kf - kfd).astype(np.float32), g_depth=rs.randn(nc, kfd).astype(np.float32))
+    keep = clean_rays(sc, cand, kc, kf, kfd, dr, n)
+    rays, dr = cand[torch.from_numpy(keep)], {k: v[keep] for k, v in dr.items()}
+    gt = torch.from_numpy(rs.uniform(0, 1, size=(n, 3)).astype(np.float32))
+    return net, sc, rays, dr, gt
+
+
+def test_backward_recompute_in_chunks(monkeypatch):
+    """A stash budget smaller than the batch: no reservation, the backward recomputes the forward and walks the rays in
+    chunks (here 0.07 GiB ~ 10 tiles of the 40 a pass needs), accumulating the weight gradients chunk by chunk."""
+    monkeypatch.setenv("PNYOLO_STASH_GB", "0.07")
+    net, sc, rays, dr, gt = _batch_for(1600, 60)
+    ren = NeRFRenderer(n_coarse=16, n_fine=8, n_fine_depth=4, white_bkgd=True).train()
+    ren.draws = dr
+    out = ren(net, rays[None].to(DEV))
+    hip = {p: {k: v[0] for k, v in out[p].items()} for p in ("coarse", "fine")}
+    render_loss(hip, gt.to(DEV)).backward()
+    ref = orc.render(sc, rays, 16, 8, 4, dr["u_coarse"], dr["u_fine"], dr["u_fine2"], dr["g_depth"])
+    render_loss(ref, gt).backward()
+    compare_param_grads(net, sc)
+
+
+def test_two_live_graphs_and_unused_outputs():
+    """(1) Two training forwards before their backwards: the second forward takes over the stash reservation, the first
+    backward falls back to recompute + immediate weight gradients; gradients accumulate into .grad as autograd does.
+    (2) A loss on fine.rgb only: the coarse pass still gets the gradient that arrives through the depth samples, and a
+    stashed pass without any gradient leaves nothing behind for the flush."""
+    net, sc, rays, dr, gt = _batch_for(1700, 40)
+    ren = NeRFRenderer(n_coarse=16, n_fine=8, n_fine_depth=4, white_bkgd=True).train()
+    ren.draws = dr
+    o1 = ren(net, rays[None].to(DEV))
+    ren.draws = dr
+    o2 = ren(net, rays[None].to(DEV))
+    l1 = torch.nn.functional.mse_loss(o1["fine"]["rgb"][0], gt.to(DEV))
+    l2 = torch.nn.functional.mse_loss(o2["coarse"]["rgb"][0], gt.to(DEV))
+    l1.backward()
+    l2.backward()
+    ref = orc.render(sc, rays, 16, 8, 4, dr["u_coarse"], dr["u_fine"], dr["u_fine2"], dr["g_depth"])
+    (torch.nn.functional.mse_loss(ref["fine"]["rgb"], gt) + torch.nn.functional.mse_loss(ref["coarse"]["rgb"], gt)).backward()
+    compare_param_grads(net, sc)
+    # fine.rgb only, depth samples detached: mlp_coarse receives nothing at all
+    net.zero_grad()
+    ren._detach_fine_depth = True
+    ren.draws = dr
+    o3 = ren(net, rays[None].to(DEV))
+    torch.nn.functional.mse_loss(o3["fine"]["rgb"][0], gt.to(DEV)).backward()
+    assert all(float(p.grad.abs().max()) == 0.0 for p in net.mlp_coarse.parameters())
+    assert any(float(p.grad.abs().max()) > 0.0 for p in net.mlp_fine.parameters())
