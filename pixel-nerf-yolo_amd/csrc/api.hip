@@ -217,6 +217,9 @@ void pny_model_destroy(pny_model* m) {
     }
     for (auto& e : m->flush_ev)
         if (e) (void)hipEventDestroy(e);
+    if (m->aux_stream) (void)hipStreamDestroy(m->aux_stream);
+    if (m->aux_fork) (void)hipEventDestroy(m->aux_fork);
+    if (m->aux_join) (void)hipEventDestroy(m->aux_join);
     m->enc.release();
     for (float* p : m->zproj_allocs) (void)hipFree(p);
     delete m;

@@ -128,6 +128,8 @@ struct pny_model {
     DevBuf dx_stash[2], ddy_stash[2], d_partial[2], d_bias[2], d_tables[2];
     PinnedStage d_stage[2];
     long long defer_cap[2] = {0, 0}, defer_used[2] = {0, 0};
+    hipStream_t aux_stream = nullptr;        // side stream of the weight-gradient GEMMs' clipped tiles (mlp_bwd.hip launch_dw_gemm)
+    hipEvent_t aux_fork = nullptr, aux_join = nullptr;
     uint64_t defer_epoch = 0;                // bumped by every pny_model_defer_weight_grads(enable)
     hipEvent_t flush_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     double flush_flops = 0.0;

@@ -247,6 +247,7 @@ constexpr int DW_LD = 260;
 constexpr int DW_TILE = 256;
 constexpr size_t DW_LDS_BYTES = (size_t)2 * 64 * DW_LD * sizeof(float);
 
+template <bool FULL>   // FULL: every item is a complete 256 x 256 tile (all 512-wide layers): predicate-free loop
 __global__ __launch_bounds__(512, 2) void pny_dw_gemm_kernel(const DwJob* __restrict__ jobs, const DwItem* __restrict__ items,
                                                              const float* __restrict__ x_stash,
                                                              const float* __restrict__ dy_stash, long long x_tile,
@@ -301,20 +302,46 @@ __global__ __launch_bounds__(512, 2) void pny_dw_gemm_kernel(const DwJob* __rest
         if (tv + 1 < it.tv_hi) fetch(tv + 1);
         const float* pa = la + hh * DW_LD + wr * 128 + l31;
         const float* px = lx + hh * DW_LD + wc * 64 + l31;
+        if constexpr (FULL) {
+            // full 256 x 256 tile (every 512-wide layer): no predicates in the loop, fragments of k-step ks + 1 are read
+            // from LDS while the 8 MFMAs of k-step ks issue
+            float av[2][4], xv[2][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) av[0][i] = pa[32 * i];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) xv[0][j] = px[32 * j];
+#pragma unroll 2
+            for (int ks = 0; ks < 32; ++ks) {
+                const int cur = ks & 1, nxt = cur ^ 1;
+                if (ks + 1 < 32) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) av[nxt][i] = pa[2 * (ks + 1) * DW_LD + 32 * i];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) xv[nxt][j] = px[2 * (ks + 1) * DW_LD + 32 * j];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    bsum[i] += av[cur][i];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], xv[cur][j], acc[i][j], 0, 0, 0);
+                }
+            }
+        } else {
 #pragma unroll 4
-        for (int ks = 0; ks < 32; ++ks) {
-            float av[4], xv[2];
+            for (int ks = 0; ks < 32; ++ks) {
+                float av[4], xv[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) av[i] = pa[2 * ks * DW_LD + 32 * i];
+                for (int i = 0; i < 4; ++i) av[i] = pa[2 * ks * DW_LD + 32 * i];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) xv[j] = px[2 * ks * DW_LD + 32 * j];
+                for (int j = 0; j < 2; ++j) xv[j] = px[2 * ks * DW_LD + 32 * j];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (live_a[i]) {
-                    bsum[i] += av[i];
+                for (int i = 0; i < 4; ++i) {
+                    if (live_a[i]) {
+                        bsum[i] += av[i];
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        if (live_x[j]) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], xv[j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < 2; ++j)
+                            if (live_x[j]) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], xv[j], acc[i][j], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -367,20 +394,36 @@ __global__ __launch_bounds__(256) void pny_dw_reduce_kernel(const DwTarget* __re
     }
 }
 
-void launch_dw_gemm(const DwJob* jobs_dev, const DwItem* items_dev, int n_items, const float* x_stash, const float* dy_stash,
-                    long long x_tile, long long dy_tile, float* partial, float* bias_partial, hipStream_t st) {
+// items_dev: n_part clipped items first (lin_in's 64 columns, lin_out's 64 rows: mostly staging, few FLOPs), then n_full
+// complete tiles.  The clipped ones run on `aux` (forked from and joined back into `st`) so that they share the chip with
+// the bulk instead of forming a tail of 60 workgroups on 256 CUs.
+void launch_dw_gemm(const DwJob* jobs_dev, const DwItem* items_dev, int n_part, int n_full, const float* x_stash,
+                    const float* dy_stash, long long x_tile, long long dy_tile, float* partial, float* bias_partial, hipStream_t st,
+                    hipStream_t aux, hipEvent_t ev_fork, hipEvent_t ev_join) {
     static bool attr_set[64] = {};
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
     dev_ &= 63;
     if (!attr_set[dev_]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pny_dw_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pny_dw_gemm_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)DW_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pny_dw_gemm_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)DW_LDS_BYTES);
         attr_set[dev_] = true;
     }
-    if (n_items <= 0) return;
-    hipLaunchKernelGGL(pny_dw_gemm_kernel, dim3(n_items), dim3(512), DW_LDS_BYTES, st, jobs_dev, items_dev, x_stash, dy_stash,
-                       x_tile, dy_tile, partial, bias_partial);
+    const bool fork = n_part > 0 && n_full > 0 && aux && ev_fork && ev_join;
+    hipStream_t sp = st;
+    if (fork && hipEventRecord(ev_fork, st) == hipSuccess && hipStreamWaitEvent(aux, ev_fork, 0) == hipSuccess) sp = aux;
+    if (n_part > 0)
+        hipLaunchKernelGGL(pny_dw_gemm_kernel<false>, dim3(n_part), dim3(512), DW_LDS_BYTES, sp, jobs_dev, items_dev, x_stash, dy_stash,
+                           x_tile, dy_tile, partial, bias_partial);
+    if (n_full > 0)
+        hipLaunchKernelGGL(pny_dw_gemm_kernel<true>, dim3(n_full), dim3(512), DW_LDS_BYTES, st, jobs_dev, items_dev + n_part, x_stash,
+                           dy_stash, x_tile, dy_tile, partial, bias_partial);
+    if (sp != st) {
+        (void)hipEventRecord(ev_join, aux);
+        (void)hipStreamWaitEvent(st, ev_join, 0);
+    }
 }
 
 void launch_dw_reduce(const DwTarget* targets_dev, int n_targets, long long max_elems, const float* partial,

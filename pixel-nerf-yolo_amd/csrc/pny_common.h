@@ -166,8 +166,9 @@ void launch_mlp_dz(const DzArgs& a, hipStream_t st);
 void launch_depth_grad_gather(const int* sel, const float* dz, const float* g_in, long long n, int kfd, float* g_out, hipStream_t st);
 void launch_yolo_aggregate_bwd(const float* raw, const float* g, long long n, int k, int na, float* d_raw, hipStream_t st);
 void launch_mlp_bwd(const BwdArgs& a, int grid, hipStream_t st);
-void launch_dw_gemm(const DwJob* jobs_dev, const DwItem* items_dev, int n_items, const float* x_stash, const float* dy_stash,
-                    long long x_tile, long long dy_tile, float* partial, float* bias_partial, hipStream_t st);
+void launch_dw_gemm(const DwJob* jobs_dev, const DwItem* items_dev, int n_part, int n_full, const float* x_stash,
+                    const float* dy_stash, long long x_tile, long long dy_tile, float* partial, float* bias_partial, hipStream_t st,
+                    hipStream_t aux, hipEvent_t ev_fork, hipEvent_t ev_join);
 void launch_dw_reduce(const DwTarget* targets_dev, int n_targets, long long max_elems, const float* partial,
                       const float* bias_partial, int accumulate, hipStream_t st);
 void launch_composite_bwd(const float* rays, const float* z, const float* samp, const float* noise, long long n, int k,

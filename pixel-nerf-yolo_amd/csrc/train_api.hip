@@ -101,7 +101,8 @@ TrainPlan build_plan(const pny_model* m, int ns, int L, const std::string& pre) 
 }
 
 // Split every job's (tile, view) range over workgroups so that the grid has ~4 workgroups per CU with equal work.
-void build_items(TrainPlan& p, int n_tiles, int cus, std::vector<DwItem>& items, long long* part_floats, long long* bias_floats) {
+void build_items(TrainPlan& p, int n_tiles, int cus, std::vector<DwItem>& items, long long* part_floats, long long* bias_floats,
+                 int* n_full) {
     items.clear();
     double total = 0.0;
     std::vector<int> otiles(p.jobs.size());
@@ -140,8 +141,19 @@ void build_items(TrainPlan& p, int n_tiles, int cus, std::vector<DwItem>& items,
         poff += (long long)splits * jb.a_rows * jb.x_cols;
         boff += (long long)splits * jb.a_rows;
     }
-    // longest first: the tail of the grid is then made of short items
-    std::stable_sort(items.begin(), items.end(), [](const DwItem& a, const DwItem& b) { return (a.tv_hi - a.tv_lo) > (b.tv_hi - b.tv_lo); });
+    // complete 256 x 256 tiles first (they run the predicate-free instantiation), clipped ones after; within each group
+    // longest first, so that the tail of the grid is made of short items
+    auto full = [&](const DwItem& it) {
+        const DwJob& jb = p.jobs[it.job];
+        return (it.mt + 1) * 256 <= jb.a_rows && (it.nt + 1) * 256 <= jb.x_cols;
+    };
+    std::stable_sort(items.begin(), items.end(), [&](const DwItem& a, const DwItem& b) {
+        const bool fa = full(a), fb = full(b);
+        if (fa != fb) return fb;   // clipped tiles (lin_in's 64 columns, lin_out's 64 rows) first: they are mostly staging
+        return (a.tv_hi - a.tv_lo) > (b.tv_hi - b.tv_lo);
+    });
+    *n_full = 0;
+    for (const DwItem& it : items) *n_full += full(it) ? 1 : 0;
     *part_floats = poff;
     *bias_floats = boff;
 }
@@ -156,12 +168,18 @@ size_t stash_budget_bytes() {
 }
 
 // Weight-gradient GEMMs over n_tiles tiles of the two stashes + deterministic split reduction into the bound gradients.
-int run_weight_grads(TrainPlan& plan, int n_tiles, const float* x_stash, const float* dy_stash, DevBuf& partial, DevBuf& bias,
-                     DevBuf& tables, PinnedStage& stage, int accumulate, hipStream_t st) {
+int run_weight_grads(pny_model* m, TrainPlan& plan, int n_tiles, const float* x_stash, const float* dy_stash, DevBuf& partial,
+                     DevBuf& bias, DevBuf& tables, PinnedStage& stage, int accumulate, hipStream_t st) {
+    if (!m->aux_stream) {
+        PNY_HIP(hipStreamCreateWithFlags(&m->aux_stream, hipStreamNonBlocking));
+        PNY_HIP(hipEventCreateWithFlags(&m->aux_fork, hipEventDisableTiming));
+        PNY_HIP(hipEventCreateWithFlags(&m->aux_join, hipEventDisableTiming));
+    }
     const int cus = mlp_max_grid(MLP_8x64);
     std::vector<DwItem> items;
     long long part_floats = 0, bias_floats = 0;
-    build_items(plan, n_tiles, cus, items, &part_floats, &bias_floats);
+    int n_full = 0;
+    build_items(plan, n_tiles, cus, items, &part_floats, &bias_floats, &n_full);
     int rc;
     if ((rc = partial.reserve((size_t)part_floats * sizeof(float)))) return rc;
     if ((rc = bias.reserve((size_t)bias_floats * sizeof(float)))) return rc;
@@ -179,8 +197,9 @@ int run_weight_grads(TrainPlan& plan, int n_tiles, const float* x_stash, const f
     memcpy(h + o_targets, plan.targets.data(), tg_bytes);
     if ((rc = stage.upload(tables.p, total, st))) return rc;
     char* tb = reinterpret_cast<char*>(tables.p);
-    launch_dw_gemm(reinterpret_cast<const DwJob*>(tb), reinterpret_cast<const DwItem*>(tb + o_items), (int)items.size(), x_stash,
-                   dy_stash, plan.lay.x_tile, plan.lay.dy_tile, partial.f(), bias.f(), st);
+    launch_dw_gemm(reinterpret_cast<const DwJob*>(tb), reinterpret_cast<const DwItem*>(tb + o_items), (int)items.size() - n_full,
+                   n_full, x_stash, dy_stash, plan.lay.x_tile, plan.lay.dy_tile, partial.f(), bias.f(), st, m->aux_stream,
+                   m->aux_fork, m->aux_join);
     PNY_HIP(hipGetLastError());
     long long max_elems = 0;
     for (const DwTarget& t : plan.targets) max_elems = std::max(max_elems, (long long)t.rows * t.cols + t.rows);
@@ -345,7 +364,7 @@ int mlp_backward(pny_scene* s, int mode, const float* xyz, const float* dirs, co
         }
         // 3. weight-gradient GEMMs over the two stashes + deterministic split reduction into the bound gradients
         if (!defer && !have_x &&
-            (rc = run_weight_grads(plan, n_tiles, x_base, dy_base, s->dw_partial, s->dw_bias, s->dw_tables, s->table_stage,
+            (rc = run_weight_grads(m, plan, n_tiles, x_base, dy_base, s->dw_partial, s->dw_bias, s->dw_tables, s->table_stage,
                                    (accumulate || p0 > 0) ? 1 : 0, st)))
             return rc;
         if ((rc = stamp())) return rc;
@@ -409,7 +428,7 @@ int pny_model_flush_weight_grads(pny_model* m, int accumulate, pny_stream stream
         PNY_HIP(hipEventRecord(m->flush_ev[2 * w], st));
         if (m->defer_used[w] > 0) {
             TrainPlan plan = build_plan(m, m->defer_ns, d.d_latent, w ? "mlp_fine." : "mlp_coarse.");
-            if ((rc = run_weight_grads(plan, (int)m->defer_used[w], m->dx_stash[w].f(), m->ddy_stash[w].f(), m->d_partial[w],
+            if ((rc = run_weight_grads(m, plan, (int)m->defer_used[w], m->dx_stash[w].f(), m->ddy_stash[w].f(), m->d_partial[w],
                                        m->d_bias[w], m->d_tables[w], m->d_stage[w], accumulate, st)))
                 return rc;
             m->flush_flops += fwd * 64.0 * (double)m->defer_used[w];
