@@ -11,6 +11,8 @@ SpatialEncoder.forward: here images -> pny_scene_encode -> pny_render, RGB / sig
 
 All tolerances in this file are ABSOLUTE 1e-4 (north_star), on fixtures whose magnitudes are O(1).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -313,3 +315,51 @@ def test_gen_rays_range_matches_full_call(golden):
     assert torch.equal(part, out.reshape(-1, 8)[325:325 + 433])
     with pytest.raises(Exception):
         gen_rays_range(poses, 20, 12, torch.tensor(35.5), 0.8, 1.8, 400, 100)   # beyond the grid
+
+
+def test_eval_from_a_dataset_directory(tmp_path):
+    """eval/eval.py:219-360 on files: SRNDataset item (pixel-nerf-yolo_amd/data.py) -> encode(source views) -> gen_rays(target
+    poses) -> render -> PNG + PSNR / SSIM; a ray subset against the oracle fed with the same item."""
+    from pixel_nerf_yolo_amd import data as pdata
+    rs = np.random.RandomState(4)
+    S, NV = 64, 4
+    d = tmp_path / "cars_test" / "obj0"
+    (d / "rgb").mkdir(parents=True)
+    (d / "pose").mkdir()
+    (d / "intrinsics.txt").write_text("%f %f %f 0.\n0. 0. 0.\n1.\n%d %d\n" % (65.6, S / 2, S / 2, S, S))
+    for v in range(NV):
+        img = np.full((S, S, 3), 255, np.uint8)
+        img[12:52, 10:54] = rs.randint(0, 250, size=(40, 44, 3))
+        pdata.imwrite(str(d / "rgb" / ("%06d.png" % v)), img)
+        np.savetxt(str(d / "pose" / ("%06d.txt" % v)), (synth.pose_spherical(40.0 * v, -20.0, 1.3) @ np.diag([1.0, -1.0, -1.0, 1.0])).reshape(1, 16))
+    item = pdata.get_split_dataset("srn", str(tmp_path / "cars"), want_split="test", training=False, image_size=(S, S))[0]
+    net = make_model(pconf.default_mv()["model"]).eval()
+    load_mlp(net.mlp_coarse, 301, 512, 4)
+    load_mlp(net.mlp_fine, 302, 512, 4)
+    esd = synth.resnet34_state(303, residual_gain=0.25)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in esd.items()}, strict=False)
+    net = net.to(DEV)
+    src, tgt = [0, 2], [1, 3]
+    images, poses, focal, c = item["images"], item["poses"], item["focal"], item["c"]
+    net.encode(images[src].unsqueeze(0), poses[src].unsqueeze(0).to(DEV), focal, c=c)
+    rays = gen_rays(poses[tgt], S, S, focal, 0.8, 1.8, c=c).reshape(1, -1, 8)
+    ren = NeRFRenderer(n_coarse=16, n_fine=8, n_fine_depth=4, white_bkgd=True).eval()
+    par = ren.bind_parallel(net, None, simple_output=True).eval()
+    n = rays.shape[1]
+    draws = dict(u_coarse=rs.rand(n, 16).astype(np.float32), u_fine=rs.rand(n, 4).astype(np.float32),
+                 u_fine2=rs.rand(n, 4).astype(np.float32), g_depth=rs.randn(n, 4).astype(np.float32))
+    ren.draws = draws
+    with torch.no_grad():
+        rgb, depth = par(rays)
+    frames = rgb[0].reshape(2, S, S, 3).cpu().numpy()
+    gt = (images[tgt] * 0.5 + 0.5).permute(0, 2, 3, 1).numpy()
+    p, s_ = pdata.write_views(str(tmp_path / "out"), frames, tgt, gt=gt)
+    assert np.isfinite(p) and 0.0 <= s_ <= 1.0 and sorted(os.listdir(tmp_path / "out")) == ["000001.png", "000003.png"]
+    # the same item through the oracle (its own trunk) on a ray subset
+    lat, _ = orc.spatial_encoder(esd, images[src].numpy())
+    sc = orc.Scene(synth.mlp_state(301), synth.mlp_state(302), lat, poses[src].numpy(), focal, c[None], S, S)
+    sub = torch.from_numpy(rs.choice(n, 96, replace=False))
+    ref = orc.render(sc, rays[0].cpu()[sub], 16, 8, 4, draws["u_coarse"][sub], draws["u_fine"][sub], draws["u_fine2"][sub],
+                     draws["g_depth"][sub])
+    diff = (rgb[0].cpu()[sub] - ref["fine"]["rgb"]).abs().max(dim=1)[0]
+    assert int((diff > TOL).sum()) <= 2 and float(diff.median()) < 1e-5
