@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PNY_ABI_VERSION 5
+#define PNY_ABI_VERSION 6
 
 typedef enum pny_status {
     PNY_OK = 0,
@@ -152,6 +152,10 @@ typedef struct pny_render_opts {
     const float* u_fine2_dev;  /* (n, n_fine-n_fine_depth) U[0,1): in-bin jitter */
     const float* g_depth_dev;  /* (n, n_fine_depth) N(0,1) */
     uint64_t seed;
+    /* Training only (src/render/nerf.py:231-232: sigmas + randn_like(sigmas) * noise_std): the noise ADDED to sigma before
+     * the composite's relu, already scaled by noise_std; (n, n_coarse) and (n, n_coarse+n_fine), or NULL (no noise). */
+    const float* sigma_noise_coarse_dev;
+    const float* sigma_noise_fine_dev;
 } pny_render_opts;
 
 /* Any output pointer may be NULL. */

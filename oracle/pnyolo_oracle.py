@@ -118,12 +118,15 @@ def sample_fine_depth(rays, depth, g, depth_std):
     return torch.max(torch.min(z, rays[:, 7:8]), rays[:, 6:7])
 
 
-def composite(rays, z, out, white_bkgd):
+def composite(rays, z, out, white_bkgd, sigma_noise=None):
     """src/render/nerf.py:184-188 (deltas, last = far - z_last) and :229-250
     (alpha, shifted cumprod transmittance, weights, rgb/depth sums, white background).
-    out (N,K,4) = per-sample [sigmoid rgb, relu sigma] from the model."""
+    out (N,K,4) = per-sample [sigmoid rgb, relu sigma] from the model.  sigma_noise (N,K): the training-time
+    `randn_like(sigmas) * noise_std` (nerf.py:231-232), a random draw like the others."""
     deltas = torch.cat([z[:, 1:] - z[:, :-1], rays[:, 7:8] - z[:, -1:]], -1)
     rgbs, sigmas = out[..., :3], out[..., 3]
+    if sigma_noise is not None:
+        sigmas = sigmas + T(sigma_noise)
     alphas = 1 - torch.exp(-deltas * torch.relu(sigmas))
     shifted = torch.cat([torch.ones_like(alphas[:, :1]), 1 - alphas + 1e-10], -1)
     Tr = torch.cumprod(shifted, -1)
@@ -314,7 +317,8 @@ def _query_rays(scene, rays, z, coarse, chunk):
 
 
 def render(scene, rays, n_coarse, n_fine, n_fine_depth, u_coarse, u_fine=None, u_fine2=None, g_depth=None,
-           depth_std=0.01, white_bkgd=True, lindisp=False, chunk=50000, detach_fine_depth=False):
+           depth_std=0.01, white_bkgd=True, lindisp=False, chunk=50000, detach_fine_depth=False, noise_coarse=None,
+           noise_fine=None):
     """src/render/nerf.py:257-309 (forward) for SB=1: coarse pass, then fine pass on
     sort(cat(z_coarse, z_fine, z_depth)) with the fine MLP.  The four random draws are inputs.
     Under autograd the reference detaches the coarse weights for importance sampling (nerf.py:132) but NOT the coarse
@@ -325,7 +329,7 @@ def render(scene, rays, n_coarse, n_fine, n_fine_depth, u_coarse, u_fine=None, u
     res = {}
     zc = sample_coarse(rays, n_coarse, u_coarse, lindisp)
     oc = _query_rays(scene, rays, zc, True, chunk)
-    wc, rgbc, dc = composite(rays, zc, oc, white_bkgd)
+    wc, rgbc, dc = composite(rays, zc, oc, white_bkgd, noise_coarse)
     res["coarse"] = dict(z=zc, out=oc, weights=wc, rgb=rgbc, depth=dc)
     if n_fine > 0:
         samps = [zc]
@@ -335,7 +339,7 @@ def render(scene, rays, n_coarse, n_fine, n_fine_depth, u_coarse, u_fine=None, u
             samps.append(sample_fine_depth(rays, dc.detach() if detach_fine_depth else dc, g_depth, depth_std))
         zf, _ = torch.sort(torch.cat(samps, dim=-1), dim=-1)
         of = _query_rays(scene, rays, zf, False, chunk)
-        wf, rgbf, df = composite(rays, zf, of, white_bkgd)
+        wf, rgbf, df = composite(rays, zf, of, white_bkgd, noise_fine)
         res["fine"] = dict(z=zf, out=of, weights=wf, rgb=rgbf, depth=df)
     return res
 

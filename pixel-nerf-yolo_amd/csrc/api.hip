@@ -887,7 +887,7 @@ int pny_render(pny_scene* s, const float* rays_dev, int64_t n, const pny_render_
     s->stashed[0].valid = s->stashed[1].valid = false;
     launch_sample_coarse(rays_dev, n, kc, o->lindisp, o->u_coarse_dev, o->seed, zc, st);
     if ((rc = run_mlp(s, 1, nullptr, nullptr, rays_dev, zc, kc, (long long)n * kc, 1, sc, st, stash ? 0 : -1))) return rc;
-    launch_composite(rays_dev, zc, sc, n, kc, o->white_bkgd, wc, rgbc, dc, st);
+    launch_composite(rays_dev, zc, sc, n, kc, o->white_bkgd, wc, rgbc, dc, st, o->sigma_noise_coarse_dev);
     if (o->n_fine > 0) {
         float* zf = out->z_fine ? out->z_fine : W + o_zf;
         float* sf = out->sample_fine ? out->sample_fine : W + o_sf;
@@ -896,7 +896,8 @@ int pny_render(pny_scene* s, const float* rays_dev, int64_t n, const pny_render_
         launch_sample_fine(rays_dev, zc, wc, dc, n, kc, o->n_fine, o->n_fine_depth, o->depth_std, o->lindisp,
                            o->u_fine_dev, o->u_fine2_dev, o->g_depth_dev, o->seed, zf, st);
         if ((rc = run_mlp(s, 1, nullptr, nullptr, rays_dev, zf, kt, (long long)n * kt, 0, sf, st, stash ? 1 : -1))) return rc;
-        launch_composite(rays_dev, zf, sf, n, kt, o->white_bkgd, out->weights_fine, out->rgb_fine, out->depth_fine, st);
+        launch_composite(rays_dev, zf, sf, n, kt, o->white_bkgd, out->weights_fine, out->rgb_fine, out->depth_fine, st,
+                         o->sigma_noise_fine_dev);
     }
     PNY_HIP(hipGetLastError());
     return PNY_OK;

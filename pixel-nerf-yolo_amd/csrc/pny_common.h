@@ -187,7 +187,7 @@ size_t mlp_scratch_floats();
 void launch_sample_coarse(const float* rays, long long n, int kc, int lindisp, const float* u, uint64_t seed,
                           float* z, hipStream_t st);
 void launch_composite(const float* rays, const float* z, const float* samp, long long n, int k, int white,
-                      float* w, float* rgb, float* depth, hipStream_t st);
+                      float* w, float* rgb, float* depth, hipStream_t st, const float* noise = nullptr);
 void launch_sample_fine(const float* rays, const float* zc, const float* w, const float* depth, long long n,
                         int kc, int kf, int kfd, float depth_std, int lindisp, const float* u, const float* u2,
                         const float* g, uint64_t seed, float* zout, hipStream_t st);

@@ -48,9 +48,11 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// noise (optional, (n, K)): the training-time draw added to sigma before the relu (reference nerf.py:231-232), already
+// scaled by noise_std.
 __global__ __launch_bounds__(256) void composite_kernel(const float* __restrict__ rays, const float* __restrict__ z,
-                                                        const float* __restrict__ samp, long long n, int K,
-                                                        int white, float* __restrict__ wout,
+                                                        const float* __restrict__ samp, const float* __restrict__ noise,
+                                                        long long n, int K, int white, float* __restrict__ wout,
                                                         float* __restrict__ rgb, float* __restrict__ depth) {
     const int lane = threadIdx.x & 63;
     const long long ray = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -70,7 +72,8 @@ __global__ __launch_bounds__(256) void composite_kernel(const float* __restrict_
             const float znext = (k + 1 < K) ? zr[k + 1] : far;
             s = sr[k];
             const float delta = znext - zk;
-            alpha = 1.0f - expf(-delta * fmaxf(s.w, 0.f));
+            const float sg = noise ? s.w + noise[ray * K + k] : s.w;
+            alpha = 1.0f - expf(-delta * fmaxf(sg, 0.f));
         }
         // inclusive product scan of (1 - alpha + 1e-10)
         float pprod = on ? (1.0f - alpha + 1e-10f) : 1.0f;
@@ -112,9 +115,9 @@ __global__ __launch_bounds__(256) void composite_kernel(const float* __restrict_
 }
 
 void launch_composite(const float* rays, const float* z, const float* samp, long long n, int k, int white,
-                      float* w, float* rgb, float* depth, hipStream_t st) {
+                      float* w, float* rgb, float* depth, hipStream_t st, const float* noise) {
     if (n == 0) return;
-    hipLaunchKernelGGL(composite_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, rays, z, samp, n, k, white,
+    hipLaunchKernelGGL(composite_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, rays, z, samp, noise, n, k, white,
                        w, rgb, depth);
 }
 

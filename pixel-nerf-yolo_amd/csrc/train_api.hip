@@ -536,8 +536,8 @@ int pny_render_backward(pny_scene* s, const float* rays_dev, int64_t n, const pn
             sel = reinterpret_cast<int*>(s->sel_tmp.p);
             launch_locate_depth_samples(rays_dev, sv->depth_coarse, o->g_depth_dev, o->seed, sv->z_fine, n, kt, kfd, o->depth_std, sel, st);
         }
-        launch_composite_bwd(rays_dev, sv->z_fine, sv->sample_fine, nullptr, n, kt, o->white_bkgd, g->rgb_fine, g->depth_fine,
-                             g->weights_fine, s->d_samp.f(), dz, st);
+        launch_composite_bwd(rays_dev, sv->z_fine, sv->sample_fine, o->sigma_noise_fine_dev, n, kt, o->white_bkgd, g->rgb_fine,
+                             g->depth_fine, g->weights_fine, s->d_samp.f(), dz, st);
         PNY_HIP(hipGetLastError());
         if ((rc = mlp_backward(s, 1, nullptr, nullptr, rays_dev, sv->z_fine, kt, (long long)n * kt, 0, s->d_samp.f(), accumulate & 1, st,
                                sel, kfd, dz, &s->stashed[1], sv->sample_fine, immediate)))
@@ -550,8 +550,8 @@ int pny_render_backward(pny_scene* s, const float* rays_dev, int64_t n, const pn
         first = false;
     }
     if (any_c || depth_path) {
-        launch_composite_bwd(rays_dev, sv->z_coarse, sv->sample_coarse, nullptr, n, kc, o->white_bkgd, g->rgb_coarse, g_depth_c,
-                             g->weights_coarse, s->d_samp.f(), nullptr, st);
+        launch_composite_bwd(rays_dev, sv->z_coarse, sv->sample_coarse, o->sigma_noise_coarse_dev, n, kc, o->white_bkgd, g->rgb_coarse,
+                             g_depth_c, g->weights_coarse, s->d_samp.f(), nullptr, st);
         PNY_HIP(hipGetLastError());
         if ((rc = mlp_backward(s, 1, nullptr, nullptr, rays_dev, sv->z_coarse, kc, (long long)n * kc, 1, s->d_samp.f(),
                                ((accumulate & 1) || (same_mlp && !first)) ? 1 : 0, st, nullptr, 0, nullptr, &s->stashed[0],

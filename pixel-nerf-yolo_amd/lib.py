@@ -32,6 +32,7 @@ class RenderOpts(C.Structure):
         ("white_bkgd", C.c_int32), ("lindisp", C.c_int32),
         ("u_coarse_dev", C.c_void_p), ("u_fine_dev", C.c_void_p), ("u_fine2_dev", C.c_void_p),
         ("g_depth_dev", C.c_void_p), ("seed", C.c_uint64),
+        ("sigma_noise_coarse_dev", C.c_void_p), ("sigma_noise_fine_dev", C.c_void_p),
     ]
 
 
@@ -113,7 +114,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 5
+ABI_VERSION = 6
 PROJECTION = {"off": 0, "on": 1, "auto": 2}
 
 

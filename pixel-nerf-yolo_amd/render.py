@@ -152,8 +152,6 @@ class NeRFRenderer(torch.nn.Module):
             self.n_coarse = self.sched[1][self.last_sched.item() - 1]
             self.n_fine = self.sched[2][self.last_sched.item() - 1]
         assert len(rays.shape) == 3
-        if self.training and self.noise_std > 0.0:
-            raise NotImplementedError("sigma noise (noise_std > 0, training only) is not implemented")
         params = model.trainable_mlp_parameters() if (torch.is_grad_enabled() and model.training) else []
         if not params:
             res, _ = self._render(model, rays, want_weights, save=False)
@@ -224,6 +222,20 @@ class NeRFRenderer(torch.nn.Module):
                     o.u_fine_dev = dev_draw("u_fine", kf - kfd)
                     o.u_fine2_dev = dev_draw("u_fine2", kf - kfd)
                     o.g_depth_dev = dev_draw("g_depth", kfd)
+                if self.training and self.noise_std > 0.0:
+                    # sigma noise (nerf.py:231-232), training only: drawn here (or replayed from draws["noise_coarse" /
+                    # "noise_fine"], unit normals) and handed to the composite kernels already scaled
+                    def noise(name, cols):
+                        if draws is not None and name in draws:
+                            t = torch.as_tensor(draws[name], dtype=torch.float32).reshape(SB, B, cols)[sb].to(dev)
+                        else:
+                            t = torch.randn(B, cols, device=dev, dtype=torch.float32)
+                        t = (t * float(self.noise_std)).contiguous()
+                        keep.append(t)
+                        return t.data_ptr()
+                    o.sigma_noise_coarse_dev = noise("noise_coarse", kc)
+                    if use_fine:
+                        o.sigma_noise_fine_dev = noise("noise_fine", kc + kf)
                 out = RenderOut()
                 out.rgb_coarse = res["coarse"]["rgb"][sb].data_ptr()
                 out.depth_coarse = res["coarse"]["depth"][sb].data_ptr()

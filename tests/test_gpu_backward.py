@@ -534,3 +534,40 @@ def test_two_live_graphs_and_unused_outputs():
     torch.nn.functional.mse_loss(o3["fine"]["rgb"][0], gt.to(DEV)).backward()
     assert all(float(p.grad.abs().max()) == 0.0 for p in net.mlp_coarse.parameters())
     assert any(float(p.grad.abs().max()) > 0.0 for p in net.mlp_fine.parameters())
+
+
+def test_render_with_sigma_noise_forward_and_backward():
+    """noise_std > 0 in train() mode (reference nerf.py:231-232): the draws are replayed on both sides."""
+    ns, H, W, kc, kf, kfd, n = 2, 32, 32, 16, 8, 4, 40
+    net, sc = scene_pair(ns, H, W, 512, 4, 5, 3, 1800)
+    _, tgt = synth.scene_cameras(ns)
+    rs = np.random.RandomState(31)
+    nc = H * W
+    cand = orc.gen_rays(tgt[None], W, H, 0.9 * W, 0.3, 1.8)[0].reshape(-1, 8)
+    dr = dict(u_coarse=rs.rand(nc, kc).astype(np.float32), u_fine=rs.rand(nc, kf - kfd).astype(np.float32),
+              u_fine2=rs.rand(nc, kf - kfd).astype(np.float32), g_depth=rs.randn(nc, kfd).astype(np.float32),
+              noise_coarse=rs.randn(nc, kc).astype(np.float32), noise_fine=rs.randn(nc, kc + kf).astype(np.float32))
+    std = 0.7
+    keep = clean_rays(sc, cand, kc, kf, kfd, dr, n, noise_coarse=dr["noise_coarse"] * std, noise_fine=dr["noise_fine"] * std)
+    rays, dr = cand[torch.from_numpy(keep)], {k: v[keep] for k, v in dr.items()}
+    gt = torch.from_numpy(rs.uniform(0, 1, size=(n, 3)).astype(np.float32))
+    ren = NeRFRenderer(n_coarse=kc, n_fine=kf, n_fine_depth=kfd, noise_std=std, white_bkgd=True).train()
+    ren.draws = dr
+    out = ren(net, rays[None].to(DEV), want_weights=True)
+    ref = orc.render(sc, rays, kc, kf, kfd, dr["u_coarse"], dr["u_fine"], dr["u_fine2"], dr["g_depth"],
+                     noise_coarse=dr["noise_coarse"] * std, noise_fine=dr["noise_fine"] * std)
+    assert maxabs(out["coarse"]["weights"][0], ref["coarse"]["weights"].detach()) < 1e-4
+    assert maxabs(out["fine"]["rgb"][0], ref["fine"]["rgb"].detach()) < 1e-4
+    quiet = orc.render(sc, rays, kc, kf, kfd, dr["u_coarse"], dr["u_fine"], dr["u_fine2"], dr["g_depth"])
+    assert maxabs(ref["coarse"]["weights"].detach(), quiet["coarse"]["weights"].detach()) > 1e-2     # the noise matters
+    hip = {p: {k: v[0] for k, v in out[p].items()} for p in ("coarse", "fine")}
+    render_loss(hip, gt.to(DEV)).backward()
+    render_loss(ref, gt).backward()
+    compare_param_grads(net, sc)
+    # eval() mode ignores noise_std, as the reference does
+    ren.eval()
+    net.eval()
+    ren.draws = dr
+    with torch.no_grad():
+        ev = ren(net, rays[None].to(DEV), want_weights=True)
+    assert maxabs(ev["coarse"]["weights"][0], quiet["coarse"]["weights"].detach()) < 1e-4
