@@ -254,14 +254,11 @@ __global__ __launch_bounds__(512, 2) void pny_dw_gemm_kernel(const DwJob* __rest
                                                              long long dy_tile, float* __restrict__ partial,
                                                              float* __restrict__ bias_partial) {
     extern __shared__ __attribute__((aligned(16))) float dw_lds[];
-    float* la = dw_lds;
-    float* lx = dw_lds + 64 * DW_LD;
     const DwItem it = items[blockIdx.x];
     const DwJob jb = jobs[it.job];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3, hh = lane >> 5, l31 = lane & 31;
     const int row0 = it.mt * DW_TILE, col0 = it.nt * DW_TILE;
-    const int m = tid & 63, kg_t = tid >> 6;  // staging: this thread's sample and first feature quad of the slab
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -277,74 +274,68 @@ __global__ __launch_bounds__(512, 2) void pny_dw_gemm_kernel(const DwJob* __rest
 #pragma unroll
     for (int j = 0; j < 2; ++j) live_x[j] = col0 + wc * 64 + 32 * j < jb.x_cols;
 
-    float4 ra[8], rx[8];
-    auto fetch = [&](int tv) {
+    // Pipeline over HALF tiles (32 samples): two LDS buffers of [32][260] x (A, X).  While the MFMAs of half h run on
+    // buffer h & 1, half h + 1 (fetched into registers one step earlier) is written to the other buffer and the global
+    // loads of half h + 2 are issued; one barrier per half.  No MFMA-idle staging phase (the single-buffered 64-sample
+    // version spent 26 % of its time in it).
+    constexpr int HB = 32 * DW_LD;                 // floats of one [32][DW_LD] image
+    auto bufA = [&](int b) { return dw_lds + (b ? 2 * HB : 0); };
+    auto bufX = [&](int b) { return dw_lds + (b ? 3 * HB : HB); };
+    const int ms = tid & 31, kg_s = tid >> 5;      // staging: this thread's sample within the half, first quad row (0..15)
+    float4 ra[4], rx[4];
+    auto fetch = [&](int h) {
+        const int tv = it.tv_lo + (h >> 1), half = h & 1;
         const int tile = tv / jb.n_views, v = tv - tile * jb.n_views;
-        const float4* ga = reinterpret_cast<const float4*>(dy_stash + (long long)tile * dy_tile + jb.a_off + (long long)v * jb.a_view) + (row0 / 4) * 64;
-        const float4* gx = reinterpret_cast<const float4*>(x_stash + (long long)tile * x_tile + jb.x_off + (long long)v * jb.x_view) + (col0 / 4) * 64;
+        const float4* ga = reinterpret_cast<const float4*>(dy_stash + (long long)tile * dy_tile + jb.a_off + (long long)v * jb.a_view) + (row0 / 4) * 64 + 32 * half + ms;
+        const float4* gx = reinterpret_cast<const float4*>(x_stash + (long long)tile * x_tile + jb.x_off + (long long)v * jb.x_view) + (col0 / 4) * 64 + 32 * half + ms;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int kg = kg_t + 8 * i;
-            ra[i] = (row0 + 4 * kg < jb.a_rows) ? ga[kg * 64 + m] : make_float4(0.f, 0.f, 0.f, 0.f);
-            rx[i] = (col0 + 4 * kg < jb.x_cols) ? gx[kg * 64 + m] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < 4; ++i) {
+            const int kg = kg_s + 16 * i;
+            ra[i] = (row0 + 4 * kg < jb.a_rows) ? ga[kg * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+            rx[i] = (col0 + 4 * kg < jb.x_cols) ? gx[kg * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    if (it.tv_lo < it.tv_hi) fetch(it.tv_lo);
-    for (int tv = it.tv_lo; tv < it.tv_hi; ++tv) {
-        __syncthreads();  // the previous tile's fragments have been read
+    auto stage = [&](int b) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int kg = kg_t + 8 * i;
-            *reinterpret_cast<float4*>(la + m * DW_LD + 4 * kg) = ra[i];
-            *reinterpret_cast<float4*>(lx + m * DW_LD + 4 * kg) = rx[i];
+        for (int i = 0; i < 4; ++i) {
+            const int kg = kg_s + 16 * i;
+            *reinterpret_cast<float4*>(bufA(b) + ms * DW_LD + 4 * kg) = ra[i];
+            *reinterpret_cast<float4*>(bufX(b) + ms * DW_LD + 4 * kg) = rx[i];
+        }
+    };
+    const int n_half = 2 * (it.tv_hi - it.tv_lo);
+    if (n_half > 0) {
+        fetch(0);
+        stage(0);
+        if (n_half > 1) fetch(1);
+        __syncthreads();
+    }
+    for (int h = 0; h < n_half; ++h) {
+        const int cb = h & 1;
+        if (h + 1 < n_half) {
+            stage(cb ^ 1);                     // half h + 1: every wave left that buffer at the previous barrier
+            if (h + 2 < n_half) fetch(h + 2);
+        }
+        const float* pa = bufA(cb) + hh * DW_LD + wr * 128 + l31;
+        const float* px = bufX(cb) + hh * DW_LD + wc * 64 + l31;
+#pragma unroll 4
+        for (int ks = 0; ks < 16; ++ks) {   // (an explicit LDS-read-ahead of one k-step measured the same: 13.9 vs 13.6 ms)
+            float av[4], xv[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) av[i] = pa[2 * ks * DW_LD + 32 * i];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) xv[j] = px[2 * ks * DW_LD + 32 * j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (FULL || live_a[i]) {
+                    bsum[i] += av[i];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        if (FULL || live_x[j]) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], xv[j], acc[i][j], 0, 0, 0);
+                }
+            }
         }
         __syncthreads();
-        if (tv + 1 < it.tv_hi) fetch(tv + 1);
-        const float* pa = la + hh * DW_LD + wr * 128 + l31;
-        const float* px = lx + hh * DW_LD + wc * 64 + l31;
-        if constexpr (FULL) {
-            // full 256 x 256 tile (every 512-wide layer): no predicates in the loop, fragments of k-step ks + 1 are read
-            // from LDS while the 8 MFMAs of k-step ks issue
-            float av[2][4], xv[2][2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) av[0][i] = pa[32 * i];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) xv[0][j] = px[32 * j];
-#pragma unroll 2
-            for (int ks = 0; ks < 32; ++ks) {
-                const int cur = ks & 1, nxt = cur ^ 1;
-                if (ks + 1 < 32) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) av[nxt][i] = pa[2 * (ks + 1) * DW_LD + 32 * i];
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) xv[nxt][j] = px[2 * (ks + 1) * DW_LD + 32 * j];
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    bsum[i] += av[cur][i];
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], xv[cur][j], acc[i][j], 0, 0, 0);
-                }
-            }
-        } else {
-#pragma unroll 4
-            for (int ks = 0; ks < 32; ++ks) {
-                float av[4], xv[2];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) av[i] = pa[2 * ks * DW_LD + 32 * i];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) xv[j] = px[2 * ks * DW_LD + 32 * j];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (live_a[i]) {
-                        bsum[i] += av[i];
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            if (live_x[j]) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], xv[j], acc[i][j], 0, 0, 0);
-                    }
-                }
-            }
-        }
     }
     // partial tile: P[split][row][col], row stride = the job's padded column count
     float* P = partial + it.part_off;

@@ -111,7 +111,12 @@ void build_items(TrainPlan& p, int n_tiles, int cus, std::vector<DwItem>& items,
         otiles[j] = ((jb.a_rows + 255) / 256) * ((jb.x_cols + 255) / 256);
         total += (double)otiles[j] * jb.n_views * n_tiles;
     }
-    const double per_item = std::max(1.0, total / (4.0 * cus));
+    double items_per_cu = 4.0;   // PNYOLO_DW_ITEMS_PER_CU: tuning knob (finer items = shorter tail, more partial sums)
+    if (const char* e = getenv("PNYOLO_DW_ITEMS_PER_CU")) {
+        const double v = atof(e);
+        if (v >= 1.0 && v <= 64.0) items_per_cu = v;
+    }
+    const double per_item = std::max(1.0, total / (items_per_cu * cus));
     long long poff = 0, boff = 0;
     for (size_t j = 0; j < p.jobs.size(); ++j) {
         const DwJob& jb = p.jobs[j];
