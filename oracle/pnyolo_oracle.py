@@ -444,7 +444,9 @@ def nms(boxes, iou_threshold, threshold):
         i = 0
         while i < len(lst):
             if float(iou_xywh(first[2:], lst[i][2:])) > thr32:
-                del lst[i]   # the iterator of the reference now points past the element that moved here
+                # list.remove(box) deletes the FIRST element equal to box: an identical row further up (still there only
+                # because the iterator skipped it) goes instead; the iterator then points past the element that moved here
+                del lst[lst.index(lst[i])]
             i += 1
     return kept, highest, above
 

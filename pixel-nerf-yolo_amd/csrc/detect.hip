@@ -171,11 +171,24 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* __restric
         if (tid == 0) {
             // `for box in lst: if ...: lst.remove(box)`: removing shifts the tail left under the
             // iterator, so the element after a removed one is never examined in this round.
+            // `lst.remove(box)` deletes the FIRST element that compares equal: an identical row that is still in the list
+            // further up (it can only be there because the iterator skipped it) goes instead of the row at hand.  Rows are
+            // sorted by confidence, so such a twin sits in the run of equal confidences right above.
             flag[0] = 0;
             int p = 1;
             while (p < m) {
                 if (flag[p]) {
-                    flag[p] = 0;  // 0 = drop
+                    int drop = p;
+                    const float* bp = boxes + (size_t)cur[p] * 6;
+                    for (int q = p - 1; q >= 1; --q) {
+                        const float* bq = boxes + (size_t)cur[q] * 6;
+                        if (bq[1] != bp[1]) break;
+                        // position q is still in the list iff it was kept so far in this round (flag 1 = keep, set below)
+                        if (flag[q] == 1 && bq[0] == bp[0] && bq[2] == bp[2] && bq[3] == bp[3] && bq[4] == bp[4] && bq[5] == bp[5])
+                            drop = q;
+                    }
+                    flag[p] = 1;
+                    flag[drop] = 0;  // 0 = drop
                     if (p + 1 < m) flag[p + 1] = 1;
                     p += 2;
                 } else {

@@ -936,6 +936,12 @@ def test_yolo_detection_tail_golden(golden):
             assert putil.calculate_tp_fp_fn(t_ref, p_ref, iou_t, conf_t, 0.2) == tuple(int(v) for v in g["c%d_tpfpfn%d" % (c, k)])
         kept_l, _, _ = putil.nms(g["c%d_p_boxes" % c].tolist(), 0.75, 0.45, device=DEV)   # list in, list out
         assert len(kept_l) == g["c%d_nms0_kept" % c].shape[0]
+    # duplicate rows: list.remove() deletes the FIRST equal row (reference util.py:719), which changes the order of the
+    # survivors when an identical row further up had been skipped by the remove-while-iterating loop
+    for k in range(2):
+        iou_t, conf_t, hc, above = (float(v) for v in g["dup_nms%d_meta" % k])
+        kept, hi, ab = putil.nms(dt(g["dup_boxes"]), iou_t, conf_t, as_tensor=True)
+        assert ab == int(above) and np.array_equal(kept.cpu().numpy(), g["dup_nms%d_kept" % k].astype(np.float32))
     with pytest.raises(ValueError):
         putil.nms([], 0.5, 0.5, device=DEV)
     assert putil.calculate_precision_recall_f1(36, 5, 0) == (36 / 41, 1.0, 2 * (36 / 41) / (36 / 41 + 1.0))

@@ -220,6 +220,16 @@ def test_yolo_detection_tail(golden):
                 tuple(int(v) for v in g["c%d_tpfpfn%d" % (c, k)])
 
 
+def test_nms_duplicate_rows(golden):
+    """list.remove() semantics (util.py:719): the first EQUAL row is deleted, not the row at hand."""
+    g = golden("yolo_tail")
+    for k in range(2):
+        iou_t, conf_t, hc, above = g["dup_nms%d_meta" % k]
+        kept, hi, ab = orc.nms(t(g["dup_boxes"]), iou_t, conf_t)
+        assert ab == int(above) and np.array_equal(np.array(kept, dtype=np.float32), g["dup_nms%d_kept" % k].astype(np.float32))
+    assert g["dup_nms0_kept"][1, 2] > 0.6      # B precedes the surviving twin: positional deletion would swap them
+
+
 def test_encoder_without_first_pool(golden):
     """conf/exp/sn64.conf of the reference: encoder.use_first_pool = False (encoder.py:145-146)."""
     g = golden("encoder_nopool")

@@ -505,6 +505,19 @@ def fixture_yolo_tail(name, seed=9):
             d["tpfpfn%d" % thr_i] = np.array([tp, fp, fn], dtype=np.int64)
         for k, v in d.items():
             cases["c%d_%s" % (ci, k)] = v
+    # duplicate rows: the reference's `bboxes_filtered.remove(box)` (util.py:719) deletes the first EQUAL row, which differs
+    # from deleting the row at hand when an identical row further up was skipped by the remove-while-iterating loop.
+    # F suppresses A and X' (= X); A's removal makes the iterator skip X; B (same confidence) sits between X and X'.
+    F_ = [0.0, 0.9, 0.50, 0.50, 0.20, 0.20]
+    A_ = [1.0, 0.8, 0.51, 0.50, 0.20, 0.20]
+    X_ = [0.0, 0.8, 0.50, 0.52, 0.20, 0.20]
+    B_ = [1.0, 0.8, 0.62, 0.62, 0.20, 0.20]
+    dup = [F_, A_, X_, B_, list(X_), [0.0, 0.7, 0.10, 0.10, 0.05, 0.05]]
+    for thr_i, iou_t in enumerate((0.5, 0.15)):
+        kept, hc, above = util.nms([list(b) for b in dup], iou_t, 0.3)
+        cases["dup_nms%d_kept" % thr_i] = np.array(kept, dtype=np.float64).reshape(-1, 6)
+        cases["dup_nms%d_meta" % thr_i] = np.array([iou_t, 0.3, hc, above], dtype=np.float64)
+    cases["dup_boxes"] = np.array(dup, dtype=np.float64)
     cases["anchors"] = anchors.numpy()
     cases["hw"] = np.array([h, w, A])
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **cases)
