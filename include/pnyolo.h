@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PNY_ABI_VERSION 6
+#define PNY_ABI_VERSION 7
 
 typedef enum pny_status {
     PNY_OK = 0,
@@ -232,6 +232,23 @@ int pny_scene_set_projection(pny_scene* s, int mode);
 /* Compute the projected maps now (coarse, and fine when the model has one) instead of lazily inside
  * the first large launch; a no-op when they are current.  Error when the mode is OFF. */
 int pny_scene_project(pny_scene* s, pny_stream stream);
+
+/* Matrix arithmetic of PROJECTED launches.  F32: v_mfma_f32_32x32x2_f32 on fp32 operands.  F16X2: every fp32 operand
+ * is split into two f16 planes, x = f16(x) + f16(x - f16(x)) (22 significant bits; the second plane may be denormal,
+ * which the matrix cores honour), and a product is x1 w1 + x2 w1 + x1 w2 on v_mfma_f32_32x32x16_f16 with fp32
+ * accumulation: the same measured error against fp64 as the fp32 matrix path (tools/ubench/split_f16_check.hip,
+ * 1.7e-6 vs 1.8e-6 at K = 512 on the network's magnitudes) at 5.3x its matrix rate; held to the same 1e-4 bar by the
+ * same golden vectors.  Values beyond the f16 range (|x| > 65504 in an activation or weight) are NOT representable: use
+ * F32 for such models.  AUTO (default; env PNYOLO_MLP_PRECISION=f32|f16x2 overrides at scene creation) currently equals
+ * F16X2: every projected launch, whatever its size, so that a ray's result does not depend on the batch it is rendered
+ * in.  Launches without projection (training forward, the reference operation order, batches below the projection
+ * threshold) always run F32; models with more than 6 residual blocks or combine_layer = 0 always run F32. */
+#define PNY_PRECISION_F32 0
+#define PNY_PRECISION_F16X2 1
+#define PNY_PRECISION_AUTO 2
+int pny_scene_set_precision(pny_scene* s, int mode);
+/* 1 when the last MLP launch of the scene ran the F16X2 kernel. */
+int pny_scene_last_precision(pny_scene* s, int* f16x2);
 
 /* Introspection for bench.py: GEMM FLOPs (2/MAC, unpadded, MLP only) of the last pny_render /
  * pny_query on this scene -- `flops` as executed by the fused kernel, `flops_reference` as the

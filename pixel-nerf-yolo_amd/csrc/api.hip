@@ -73,6 +73,25 @@ static void pack_layer(const float* W, int n_out, int k_in, int k_pad, std::vect
                 }
 }
 
+// Split-f16 image of a layer for mlp_h2.hip: w = w1 + w2, w1 = f16(w), w2 = f16(w - w1) (round to nearest); per 16-k step
+// [n-tile][plane][lane] x 8 halves, lane l holding W[32 nt + (l & 31)][16 j + 8 (l >> 5) + 0..7].  4 bytes per weight.
+static void pack_layer_h2(const float* W, int n_out, int k_in, int k_pad, std::vector<float>& dst) {
+    const int J = k_pad / 16, NT = n_out / 32;
+    const size_t base = dst.size();
+    dst.resize(base + (size_t)J * NT * 2 * 64 * 4);
+    _Float16* o = reinterpret_cast<_Float16*>(dst.data() + base);
+    for (int j = 0; j < J; ++j)
+        for (int nt = 0; nt < NT; ++nt)
+            for (int p = 0; p < 2; ++p)
+                for (int l = 0; l < 64; ++l)
+                    for (int r = 0; r < 8; ++r) {
+                        const int n = 32 * nt + (l & 31), k = 16 * j + 8 * (l >> 5) + r;
+                        const float w = (k < k_in) ? W[(size_t)n * k_in + k] : 0.0f;
+                        const _Float16 w1 = (_Float16)w;
+                        *o++ = p == 0 ? w1 : (_Float16)(w - (float)w1);
+                    }
+}
+
 static const HostTensor* find(const pny_model* m, const std::string& name) {
     auto it = m->host.find(name);
     return it == m->host.end() ? nullptr : &it->second;
@@ -167,6 +186,22 @@ static int pack_mlp(pny_model* m, const std::string& pre, MlpWeights& w, MlpWeig
         m->repack.push_back({PACK_AT, name, "", off, nullptr, n_out, k_in, n_out == HID ? HID : D_IN_PAD, 0});
         return 0;
     };
+    // split-f16 images for the f16x2 kernel (mlp_h2.hip)
+    auto packed_h2 = [&](const std::string& name, int k_in, int k_pad, const float** slot) -> int {
+        if ((rc = need(m, name, {HID, k_in}, &t))) return rc;
+        while (plan.blob.size() % 16) plan.blob.push_back(0.f);
+        const size_t off = plan.blob.size();
+        pack_layer_h2(t->data.data(), HID, k_in, k_pad, plan.blob);
+        plan.fix.push_back({slot, off});
+        m->repack.push_back({PACK_H2, name, "", off, nullptr, HID, k_in, k_pad, 0});
+        return 0;
+    };
+    if ((rc = packed_h2(pre + "lin_in.weight", d_in, D_IN_PAD, &wt.h2_in))) return rc;
+    for (int b = 0; b < d.n_blocks; ++b) {
+        const std::string p = pre + "blocks." + std::to_string(b);
+        if ((rc = packed_h2(p + ".fc_0.weight", HID, HID, &wt.h2_fc0[b]))) return rc;
+        if ((rc = packed_h2(p + ".fc_1.weight", HID, HID, &wt.h2_fc1[b]))) return rc;
+    }
     if (d.d_out > D_IN_PAD) return fail(PNY_ERR_ARG, "d_out > 64");
     if ((rc = plain(pre + "lin_in.weight", {HID, d_in}, &wt.w_in_plain))) return rc;
     if ((rc = packedT(pre + "lin_out.weight", d.d_out, HID, &wt.wT_out))) return rc;
@@ -335,8 +370,8 @@ int pny_model_refresh(pny_model* m, pny_stream stream) {
             j.n_out = e.n_out;
             j.k_in = e.k_in;
             j.k_pad = e.k_pad;
-            if (e.kind == PACK_A || e.kind == PACK_NT)
-                j.count = (e.n_out / 32) * (e.k_pad / 8) * 64;       // float4 elements
+            if (e.kind == PACK_A || e.kind == PACK_NT || e.kind == PACK_H2)
+                j.count = (e.n_out / 32) * (e.k_pad / 8) * 64;       // 16-byte elements
             else if (e.kind == PACK_AT)
                 j.count = (e.k_in / 32) * (e.k_pad / 8) * 64;
             else
@@ -387,6 +422,10 @@ int pny_scene_create(pny_scene** out, pny_model* m) {
     if (const char* e = getenv("PNYOLO_PROJECTION")) {  // process-wide default: off | on | auto
         if (!strcmp(e, "off")) s->zp_mode = PNY_PROJECTION_OFF;
         if (!strcmp(e, "on")) s->zp_mode = PNY_PROJECTION_ON;
+    }
+    if (const char* e = getenv("PNYOLO_MLP_PRECISION")) {  // process-wide default: f32 | f16x2 | auto
+        if (!strcmp(e, "f32")) s->precision = PNY_PRECISION_F32;
+        if (!strcmp(e, "f16x2")) s->precision = PNY_PRECISION_F16X2;
     }
     *out = s;
     return PNY_OK;
@@ -659,6 +698,14 @@ int fill_mlp_args(pny_scene* s, int mode, const float* xyz, const float* dirs, c
     memset(&a, 0, sizeof(a));
     const bool fine_w = !(coarse || !d.has_fine || !s->m->use_fine);
     a.w = fine_w ? s->m->fine : s->m->coarse;
+    {
+        const MlpWeightsT& wt = fine_w ? s->m->fine_t : s->m->coarse_t;
+        a.h2_in = wt.h2_in;
+        for (int b = 0; b < d.n_blocks; ++b) {
+            a.h2_fc0[b] = wt.h2_fc0[b];
+            a.h2_fc1[b] = wt.h2_fc1[b];
+        }
+    }
     a.w_base = s->m->packed.f();
     a.w_bytes = (unsigned)s->m->packed.bytes;
     a.latent = s->latent.f();
@@ -752,7 +799,12 @@ static int run_mlp(pny_scene* s, int mode, const float* xyz, const float* dirs, 
     }
     if ((rc = ensure_projection(s, fine_w ? 1 : 0, n_points, st, &a.zp))) return rc;
     a.tap_stride = a.zp ? a.zp_stride : s->L;
-    const int variant = mlp_pick_variant(n_points);
+    int variant = mlp_pick_variant(n_points);
+    // f16x2 kernel (split-f16 operands, mlp_h2.hip): every projected launch unless the scene is pinned to F32 -- one
+    // arithmetic for all projected launches keeps a ray's result independent of the batch it is rendered in (ray
+    // sharding stays bit-exact); a lone 64-sample h2 tile is also faster than the 32-sample fp32 shape it replaces.
+    const bool use_h2 = a.zp && mlp_h2_supports(d.n_blocks, d.combine_layer) && s->precision != PNY_PRECISION_F32;
+    if (use_h2) variant = MLP_8x64;
     const int tm = mlp_tile_samples(variant);
     const long long tiles = (n_points + tm - 1) / tm;
     if (tiles > 0x7fffffffll) return fail(PNY_ERR_ARG, "too many points for one launch");
@@ -772,12 +824,16 @@ static int run_mlp(pny_scene* s, int mode, const float* xyz, const float* dirs, 
         }
         PNY_HIP(hipEventRecord(s->ev[s->ev_used], st));
     }
-    launch_mlp(a, variant, grid, st);
+    if (use_h2)
+        launch_mlp_h2(a, grid, st);
+    else
+        launch_mlp(a, variant, grid, st);
     PNY_HIP(hipGetLastError());
     if (s->timing) {
         PNY_HIP(hipEventRecord(s->ev[s->ev_used + 1], st));
         s->ev_used += 2;
     }
+    s->last_f16x2 = use_h2;
     s->last_flops += mlp_flops_per_point(d, s->ns, a.zp == nullptr) * (double)n_points;
     s->last_flops_ref += mlp_flops_per_point(d, s->ns, true) * (double)n_points;
     s->last_projected = a.zp != nullptr;
@@ -937,6 +993,20 @@ int pny_scene_set_projection(pny_scene* s, int mode) {
     if (mode != PNY_PROJECTION_OFF && mode != PNY_PROJECTION_ON && mode != PNY_PROJECTION_AUTO)
         return fail(PNY_ERR_ARG, "pny_scene_set_projection: mode must be PNY_PROJECTION_{OFF,ON,AUTO}");
     s->zp_mode = mode;
+    return PNY_OK;
+}
+
+int pny_scene_set_precision(pny_scene* s, int mode) {
+    if (!s) return fail(PNY_ERR_ARG, "pny_scene_set_precision: null scene");
+    if (mode != PNY_PRECISION_F32 && mode != PNY_PRECISION_F16X2 && mode != PNY_PRECISION_AUTO)
+        return fail(PNY_ERR_ARG, "pny_scene_set_precision: mode must be PNY_PRECISION_{F32,F16X2,AUTO}");
+    s->precision = mode;
+    return PNY_OK;
+}
+
+int pny_scene_last_precision(pny_scene* s, int* f16x2) {
+    if (!s || !f16x2) return fail(PNY_ERR_ARG, "pny_scene_last_precision: null argument");
+    *f16x2 = s->last_f16x2 ? 1 : 0;
     return PNY_OK;
 }
 

@@ -99,6 +99,9 @@ struct MlpWeightsT {
     const float* wT_out;
     const float* wT_fc0[MAX_BLOCKS];
     const float* wT_fc1[MAX_BLOCKS];
+    const float* h2_in;       // split-f16 images (mlp_h2.hip)
+    const float* h2_fc0[MAX_BLOCKS];
+    const float* h2_fc1[MAX_BLOCKS];
 };
 
 }  // namespace pny
@@ -156,6 +159,8 @@ struct pny_scene {
     bool zp_valid[2] = {false, false};
     uint64_t zp_generation = 0;
     int zp_mode = PNY_PROJECTION_AUTO;
+    int precision = PNY_PRECISION_AUTO;   // matrix arithmetic of projected launches (pny_scene_set_precision)
+    bool last_f16x2 = false;
     bool last_projected = false;
     double last_flops_ref = 0.0;
     // timing of the MLP launches of the last call

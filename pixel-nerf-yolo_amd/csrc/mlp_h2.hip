@@ -1,0 +1,507 @@
+// The fused conditioned-MLP kernel on the f16 matrix cores with SPLIT fp32 operands (gfx950, MI355X).
+//
+// fp32 = two f16 planes: x1 = f16(x) (round to nearest), x2 = f16(x - x1): 22 significant bits, and because f16 denormals are
+// honoured the second plane keeps an ABSOLUTE precision of 2^-25 for |x| < 0.25 -- measured on the ResnetFC's magnitudes
+// (tools/ubench/split_f16_check.hip, K = 512): max |error| against fp64 of
+//     x1 w1 + x1 w2 + x2 w1   (three v_mfma_f32_32x32x16_f16 per 16 k, fp32 accumulation)          1.69e-6
+//     v_mfma_f32_32x32x2_f32 (the exact-fp32 path of mlp.hip)                                       1.79e-6
+// i.e. the same error as the fp32 matrix path, at 3 x 32 cycles per 16 k instead of 8 x 64: 5.3x the matrix rate.
+// The 1e-4 parity bar is held by the same golden vectors (tests run this kernel under PNYOLO_MLP_PRECISION=f16x2).
+//
+// Same structure as pny_mlp_kernel<Cfg<2,2>, ZP = true> (mlp.hip): 8 waves, 64 samples x 512 features per workgroup, wave w owns
+// features [64 w, 64 w + 64) (2 x 2 accumulator tiles of 32 x 32), the residual stream in the accumulators, persistent over
+// tiles, weights as one stream per wave through a static-slot register ring across layer boundaries, projected-latent
+// variant only (lin_z applied per latent pixel once per scene).  What changes:
+//   * the LDS activation buffer holds the two f16 planes of relu(.), [k/8][plane][sample] x 16 bytes (same 128 KiB); a B
+//     fragment of a 16-k step is one ds_read_b128 per plane; the epilogue splits in registers and writes 8 bytes per plane
+//     and accumulator quad;
+//   * weights are packed per 16-k step as [n-tile][plane][lane] x 16 bytes (4 bytes per weight, as before);
+//   * the interpolated projection (fp32) is staged in the very bytes its consumer lane later overwrites with the planes of
+//     relu(h): the first two floats of a feature quad in the quad's plane-0 slot, the other two in its plane-1 slot, so the
+//     block entry needs no barrier between reading the projection and writing the planes;
+//   * biases are applied lazily in the epilogue that follows (b_in + b_z0 and b_fc1[b-1] + b_z[b] at the next block entry,
+//     b_fc0 in the relu(net) epilogue, the last b_fc1 before lin_out) from a table in the remaining LDS (22 KiB for 5 blocks;
+//     152 of the CU's 160 KiB in use): no bias registers, no global loads between a barrier and a GEMM.  (mean over views of (h_v + b) = mean(h_v) + b, so the last per-view bias may follow the mean.)
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "mlp_core.h"
+
+namespace pny {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+namespace h2 {
+#ifndef PNY_H2_WD
+#define PNY_H2_WD 4
+#endif
+constexpr int NT = 2, MT = 2, TM = 64, THREADS = 512, WD = PNY_H2_WD;  // WD = ring depth in 16-k steps
+constexpr int ROW_BYTES = TM * 16;          // one plane of one row (8 features x 64 samples x f16)
+constexpr int ACT_BYTES = 64 * 2 * ROW_BYTES;  // activation buffer: [row = feature / 8][plane][sample] x 16 bytes = 128 KiB
+constexpr int TAP_BYTES = 32 * TM;             // tap table
+constexpr int MAX_NB = 6;                      // bias table: (1 + 2 n_blocks) x 512 floats must fit the 160 KiB with the rest
+__host__ __device__ constexpr int lds_bytes(int n_blocks) { return ACT_BYTES + TAP_BYTES + (1 + 2 * n_blocks) * HID * 4; }
+using C = Cfg<2, 2>;
+}  // namespace h2
+
+struct H2Seg {
+    unsigned off;  // byte offset of fragment (step 0, this wave's first n-tile, plane 0) in the weight blob
+    int jn;        // 16-k steps
+};
+__device__ __forceinline__ H2Seg h2seg(const WStream& ws, const float* packed, int jn, int wave) {
+    H2Seg s;
+    s.off = (unsigned)(reinterpret_cast<const char*>(packed) - ws.base) + (unsigned)((h2::NT * wave) * 2 * 64) * 16u;
+    s.jn = jn;
+    return s;
+}
+// fragment (step j, local n-tile nt, plane p): this lane's 16 bytes = 8 halves W[32 nt_g + (l & 31)][16 j + 8 (l >> 5) + 0..7]
+__device__ __forceinline__ h8 h2load(const WStream& ws, unsigned seg_off, int nt, int p, int j) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.lane_off, seg_off + (unsigned)(((j * 16 + nt) * 2 + p) * 64) * 16u, 0);
+    return __builtin_bit_cast(h8, v);
+}
+struct H2Ring {
+    h8 f[h2::WD][h2::NT][2];
+};
+__device__ __forceinline__ void h2ring_fill(H2Ring& r, const WStream& ws, const H2Seg& s) {
+#pragma unroll
+    for (int d = 0; d + 1 < h2::WD; ++d) {
+        const int j = d < s.jn ? d : s.jn - 1;
+#pragma unroll
+        for (int nt = 0; nt < h2::NT; ++nt)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) r.f[d][nt][p] = h2load(ws, s.off, nt, p, j);
+    }
+#pragma unroll
+    for (int nt = 0; nt < h2::NT; ++nt)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) r.f[h2::WD - 1][nt][p] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+}
+
+// acc += W_slice . act over segment `cur` (its 16-k steps a multiple of the ring depth); leaves the ring holding the first
+// WD - 1 steps of `next`.  Per step and accumulator tile: x1 w1 + x2 w1 + x1 w2.  Static ring slots as in gemm_run
+// (mlp_core.h): slot d is consumed by step j + d while slot d - 1 is refilled with step j + d - 1 + WD.
+__device__ __forceinline__ void h2gemm(f32x16 (&acc)[h2::NT][h2::MT], H2Ring& r, const WStream& ws, const H2Seg& cur,
+                                       const H2Seg& next, const char* planes, int lane, int which = 0) {
+    using namespace h2;
+    const int m0 = lane & 31, hh = lane >> 5;
+    const char* bp = planes + hh * (2 * ROW_BYTES) + m0 * 16;   // row 2 j + hh, plane 0, sample m0
+    const int jn = cur.jn, jl = jn - 1;
+    h8 B[2][MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) B[0][mt][p] = *reinterpret_cast<const h8*>(bp + p * ROW_BYTES + 32 * mt * 16);
+    for (int j = 0; j < jn; j += WD) {
+#pragma unroll
+        for (int d = 0; d < WD; ++d) {
+            const int jd = j + d;
+            const int j1 = (jd + 1 < jl) ? jd + 1 : jl;
+            const char* bj = bp + j1 * (4 * ROW_BYTES);
+            __builtin_amdgcn_sched_barrier(0);
+            const int dp = (d + WD - 1) % WD;
+            const int jj = jd - 1 + WD;
+            const bool in_cur = jj < jn;
+            const int jx = in_cur ? jj : jj - jn;
+            const unsigned src = in_cur ? cur.off : next.off;
+            // Three groups of four INDEPENDENT MFMAs (x1 w1, then x2 w1, then x1 w2 over the four accumulator tiles),
+            // fenced so the scheduler cannot regroup them by accumulator (dependent MFMAs back to back stall the matrix
+            // pipe).  The weight loads of the step ride in the first group, the LDS reads of the next step's B fragments
+            // in the other two.
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) r.f[dp][nt][p] = h2load(ws, src, nt, p, jx);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r.f[d][nt][0], B[d & 1][mt][0], acc[nt][mt], 0, 0, 0);
+#ifndef PNY_H2_NOSCHED
+#pragma unroll
+            for (int i = 0; i < NT * MT; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);
+            }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) B[(d + 1) & 1][0][p] = *reinterpret_cast<const h8*>(bj + p * ROW_BYTES);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r.f[d][nt][0], B[d & 1][mt][1], acc[nt][mt], 0, 0, 0);
+#ifndef PNY_H2_NOSCHED
+#pragma unroll
+            for (int i = 0; i < NT * MT; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (i < 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);
+            }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) B[(d + 1) & 1][1][p] = *reinterpret_cast<const h8*>(bj + p * ROW_BYTES + 32 * 16);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r.f[d][nt][1], B[d & 1][mt][0], acc[nt][mt], 0, 0, 0);
+#ifndef PNY_H2_NOSCHED
+#pragma unroll
+            for (int i = 0; i < NT * MT; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (i < 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);
+            }
+#endif
+            // keep this step's B fragments allocated until here: the fragments of step d + 1 (read from LDS during this
+            // step) must not be given registers that MFMAs of this step still have to read
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) asm volatile("" ::"v"(B[d & 1][mt][p]));
+        }
+    }
+#ifdef PNY_H2_SLEEP
+    __builtin_amdgcn_s_sleep(PNY_H2_SLEEP);
+#endif
+#ifdef PNY_H2_PARANOID
+    if (PNY_H2_PARANOID & which) __syncthreads();
+#endif
+#ifdef PNY_H2_WAIT
+    if (PNY_H2_WAIT & which) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+}
+
+// split 4 fp32 values into the two f16 planes (round to nearest)
+__device__ __forceinline__ void split4(float a, float b, float c, float d, h4& p0, h4& p1) {
+    p0[0] = (_Float16)a;
+    p0[1] = (_Float16)b;
+    p0[2] = (_Float16)c;
+    p0[3] = (_Float16)d;
+    p1[0] = (_Float16)(a - (float)p0[0]);
+    p1[1] = (_Float16)(b - (float)p0[1]);
+    p1[2] = (_Float16)(c - (float)p0[2]);
+    p1[3] = (_Float16)(d - (float)p0[3]);
+}
+
+// The 8-byte slot of feature quad (row, half) = (feature / 8, (feature / 4) & 1) of sample m in plane p is at byte
+//     (2 row + p) * ROW_BYTES + 16 m + 8 half.
+
+// Block entry / GEMM epilogue: acc += bias (+ the staged fp32 projection, ADDZ), then the planes of relu(acc) go to the
+// slots of the lane's own feature quads -- the bytes the staged projection was read from, so no other lane's data is touched.
+// `bias`: a 512-float vector of the workgroup's LDS bias table.
+template <bool ADDZ>
+__device__ __forceinline__ void h2epilogue(f32x16 (&acc)[h2::NT][h2::MT], const float* bias, char* planes, int wave, int lane) {
+    using namespace h2;
+    const int m0 = lane & 31, hh = lane >> 5;
+    const float* bl = bias + 32 * NT * wave + 4 * hh;
+    // accumulator quad (nt, q) of this lane = features 32 NT wave + 32 nt + 8 q + 4 hh + 0..3: row 4 NT wave + 4 nt + q, half hh
+    char* base = planes + (4 * NT * wave) * (2 * ROW_BYTES) + m0 * 16 + 8 * hh;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                char* s0 = base + (4 * nt + q) * (2 * ROW_BYTES) + 32 * mt * 16;
+                char* s1 = s0 + ROW_BYTES;
+                const float4 b = *reinterpret_cast<const float4*>(bl + 32 * nt + 8 * q);
+                float x0 = acc[nt][mt][4 * q + 0] + b.x, x1 = acc[nt][mt][4 * q + 1] + b.y;
+                float x2 = acc[nt][mt][4 * q + 2] + b.z, x3 = acc[nt][mt][4 * q + 3] + b.w;
+                if (ADDZ) {
+                    const float2 za = *reinterpret_cast<const float2*>(s0), zb = *reinterpret_cast<const float2*>(s1);
+                    x0 += za.x;
+                    x1 += za.y;
+                    x2 += zb.x;
+                    x3 += zb.y;
+                }
+                acc[nt][mt][4 * q + 0] = x0;
+                acc[nt][mt][4 * q + 1] = x1;
+                acc[nt][mt][4 * q + 2] = x2;
+                acc[nt][mt][4 * q + 3] = x3;
+                h4 p0, p1;
+                split4(relu1(x0), relu1(x1), relu1(x2), relu1(x3), p0, p1);
+                *reinterpret_cast<h4*>(s0) = p0;
+                *reinterpret_cast<h4*>(s1) = p1;
+            }
+}
+
+template <int NT_, int MT_>
+__device__ __forceinline__ void h2zero(f32x16 (&t)[NT_][MT_]) {
+#pragma unroll
+    for (int nt = 0; nt < NT_; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT_; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[nt][mt][r] = 0.f;
+}
+
+// gather_commit (mlp_core.h) for the staging layout above: chunk c covers feature quads [32 c, 32 c + 32)
+__device__ __forceinline__ void h2gather_commit(const GatherTaps<h2::C, 1>& g, char* planes, int chunk, int wave, int lane) {
+    using namespace h2;
+    constexpr int NMB = GatherTaps<C>::NMB, QSTEP = GatherTaps<C>::QSTEP;
+    const int m = (wave % NMB) * 8 + (lane & 7);
+    // quad 32 chunk + 8 qb + (lane >> 3): row 16 chunk + 4 qb + (lane >> 4), half (lane >> 3) & 1
+    char* base = planes + (16 * chunk + (lane >> 4)) * (2 * ROW_BYTES) + m * 16 + 8 * ((lane >> 3) & 1);
+#pragma unroll
+    for (int i = 0; i < GatherTaps<C>::QPW; ++i) {
+        const int qb = wave / NMB + i * QSTEP;
+        const float4(&x)[4] = g.x[0][i];
+        float2 lo, hi;
+        lo.x = __builtin_fmaf(x[3].x, g.w[3], __builtin_fmaf(x[2].x, g.w[2], __builtin_fmaf(x[1].x, g.w[1], x[0].x * g.w[0])));
+        lo.y = __builtin_fmaf(x[3].y, g.w[3], __builtin_fmaf(x[2].y, g.w[2], __builtin_fmaf(x[1].y, g.w[1], x[0].y * g.w[0])));
+        hi.x = __builtin_fmaf(x[3].z, g.w[3], __builtin_fmaf(x[2].z, g.w[2], __builtin_fmaf(x[1].z, g.w[1], x[0].z * g.w[0])));
+        hi.y = __builtin_fmaf(x[3].w, g.w[3], __builtin_fmaf(x[2].w, g.w[2], __builtin_fmaf(x[1].w, g.w[1], x[0].w * g.w[0])));
+#ifdef PNY_H2_NOGATHER
+#if PNY_H2_NOGATHER == 1
+        lo = make_float2(0.f, 0.f);
+        hi = make_float2(0.f, 0.f);
+#elif PNY_H2_NOGATHER == 2   // weights only (tap table)
+        lo = make_float2(g.w[0], g.w[1]);
+        hi = make_float2(g.w[2], g.w[3]);
+#elif PNY_H2_NOGATHER == 3   // data of tap 0 only
+        lo = make_float2(x[0].x, x[0].y);
+        hi = make_float2(x[0].z, x[0].w);
+#elif PNY_H2_NOGATHER >= 16   // only the chunks in the mask (PNY_H2_NOGATHER - 16)
+        if (!(((PNY_H2_NOGATHER - 16) >> chunk) & 1)) {
+            lo = make_float2(0.f, 0.f);
+            hi = make_float2(0.f, 0.f);
+        }
+#elif PNY_H2_NOGATHER == 4   // tap offsets only
+        lo = make_float2((float)(g.t[0] - g.t[1]) * 1e-6f, (float)(g.t[2] - g.t[3]) * 1e-6f);
+        hi = lo;
+#endif
+#endif
+        char* s0 = base + (4 * qb) * (2 * ROW_BYTES);
+        *reinterpret_cast<float2*>(s0) = lo;
+        *reinterpret_cast<float2*>(s0 + ROW_BYTES) = hi;
+    }
+}
+
+// per (view, tile) prologue: the lin_in B operand (positional code, view dirs) as f16 planes in rows 0..7 of each plane, and
+// the tap table; the arithmetic of prologue<C>() in mlp_core.h
+__device__ __forceinline__ void h2prologue(const MlpArgs& a, int v, long long tile, char* planes, float4* tap_tab, int tid) {
+    using namespace h2;
+    constexpr int NPART = THREADS / TM;
+    const int m = tid % TM, part = tid / TM;
+    long long s = tile * TM + m;
+    if (s >= a.n_points) s = a.n_points - 1;
+    float p[3], d[3];
+    load_point(a, s, p, d);
+    const Cam cam = a.cams[v];
+    float xr[3], xc[3], vd[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        xr[i] = cam.w2c[4 * i + 0] * p[0] + cam.w2c[4 * i + 1] * p[1] + cam.w2c[4 * i + 2] * p[2];
+        xc[i] = xr[i] + cam.w2c[4 * i + 3];
+        vd[i] = cam.w2c[4 * i + 0] * d[0] + cam.w2c[4 * i + 1] * d[1] + cam.w2c[4 * i + 2] * d[2];
+    }
+    for (int g = part; g < D_IN_PAD / 4; g += NPART) {
+        h4 p0, p1;
+        split4(input_entry(4 * g + 0, xr, vd, a.freq_factor, a.num_freqs), input_entry(4 * g + 1, xr, vd, a.freq_factor, a.num_freqs),
+               input_entry(4 * g + 2, xr, vd, a.freq_factor, a.num_freqs), input_entry(4 * g + 3, xr, vd, a.freq_factor, a.num_freqs), p0, p1);
+        char* s0 = planes + (g >> 1) * (2 * ROW_BYTES) + m * 16 + 8 * (g & 1);
+        *reinterpret_cast<h4*>(s0) = p0;
+        *reinterpret_cast<h4*>(s0 + ROW_BYTES) = p1;
+    }
+    if (part == NPART - 1) {
+        float ux, uy;
+        if (!a.yolo) {
+            ux = -xc[0] / xc[2];
+            uy = -xc[1] / xc[2];
+        } else {
+            ux = xc[0] / xc[2];
+            uy = xc[1] / xc[2];
+        }
+        ux = ux * cam.fx + cam.cx;
+        uy = uy * cam.fy + cam.cy;
+        const float gx = ux * a.sx - 1.0f, gy = uy * a.sy - 1.0f;
+        const float ix = ((gx + 1.0f) / 2.0f) * (float)(a.Wl - 1);
+        const float iy = ((gy + 1.0f) / 2.0f) * (float)(a.Hl - 1);
+        const float x0 = floorf(ix), y0 = floorf(iy);
+        const float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
+        float wgt[4] = {(x1 - ix) * (y1 - iy), (ix - x0) * (y1 - iy), (x1 - ix) * (iy - y0), (ix - x0) * (iy - y0)};
+        const float xs[4] = {x0, x1, x0, x1};
+        const float ys[4] = {y0, y0, y1, y1};
+        const bool cull = a.yolo && !(xc[2] < 0.0f);
+        int offs[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool ok = (xs[k] >= 0.f) && (xs[k] <= (float)(a.Wl - 1)) && (ys[k] >= 0.f) && (ys[k] <= (float)(a.Hl - 1));
+            offs[k] = 0;
+            if (ok)
+                offs[k] = ((int)ys[k] * a.Wl + (int)xs[k]) * a.tap_stride;
+            else
+                wgt[k] = wgt[k] * 0.0f;
+            if (cull || (a.yolo && (wgt[k] != wgt[k]))) wgt[k] = 0.0f;
+        }
+        tap_tab[2 * m] = make_float4(__int_as_float(offs[0]), __int_as_float(offs[1]), __int_as_float(offs[2]), __int_as_float(offs[3]));
+        tap_tab[2 * m + 1] = make_float4(wgt[0], wgt[1], wgt[2], wgt[3]);
+    }
+}
+
+__global__ __launch_bounds__(h2::THREADS, 2) void pny_mlp_h2_kernel(const MlpArgs a) {
+    using namespace h2;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    char* planes = smem_raw;
+    float4* tap_tab = reinterpret_cast<float4*>(smem_raw + ACT_BYTES);
+    float* bias_tab = reinterpret_cast<float*>(smem_raw + ACT_BYTES + TAP_BYTES);   // [b_in, b_fc0[0], b_fc1[0], b_fc0[1], ...][512]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* slab = a.scratch + (size_t)blockIdx.x * (TM * HID) + (size_t)wave * (NT * MT * 16 * 64) + 4 * lane;
+    const int nb = a.n_blocks;
+    const int nvb = a.combine_layer < nb ? a.combine_layer : nb;   // >= 1 (the host only selects this kernel with a projection)
+    const WStream ws = wstream(a, lane);
+    const H2Seg s_in = h2seg(ws, a.h2_in, D_IN_PAD / 16, wave);
+    auto fc0seg = [&](int b) { return h2seg(ws, a.h2_fc0[b], HID / 16, wave); };
+    auto fc1seg = [&](int b) { return h2seg(ws, a.h2_fc1[b], HID / 16, wave); };
+    // bias applied at the entry of block b (b = n_blocks: before lin_out): b_in, or the previous block's b_fc1 -- the host
+    // (api.hip pack_mlp) has folded the block's lin_z bias into either
+    auto entry_bias = [&](int b) { return bias_tab + (b == 0 ? 0 : 2 * b) * HID; };
+    auto fc0_bias = [&](int b) { return bias_tab + (1 + 2 * b) * HID; };
+    H2Ring ring;
+    h2ring_fill(ring, ws, s_in);
+    for (int i = tid; i < (1 + 2 * nb) * HID; i += THREADS) {
+        const int vec = i / HID, f = i % HID;
+        const float* src = vec == 0 ? a.w.b_in : ((vec & 1) ? a.w.b_fc0[(vec - 1) >> 1] : a.w.b_fc1[(vec - 2) >> 1]);
+        bias_tab[i] = src[f];
+    }
+
+    const bool xcd_order = (gridDim.x & 7) == 0;   // see mlp.hip
+    const long long t_chunk = xcd_order ? (a.n_tiles + 7) / 8 : a.n_tiles;
+    const long long t_first = xcd_order ? (long long)(blockIdx.x & 7) * t_chunk + (blockIdx.x >> 3) : blockIdx.x;
+    const long long t_last = xcd_order ? ((long long)((blockIdx.x & 7) + 1) * t_chunk < a.n_tiles
+                                              ? (long long)((blockIdx.x & 7) + 1) * t_chunk : (long long)a.n_tiles)
+                                       : (long long)a.n_tiles;
+    const int t_step = xcd_order ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    for (long long tile = t_first; tile < t_last; tile += t_step) {
+        f32x16 h[NT][MT];
+        f32x16 net[NT][MT];
+        // one residual block from "planes hold relu(h_in)" on: net = fc_0(.), h += fc_1(relu(net + b_fc0))
+        auto block_tail = [&](int blk, const H2Seg& after, const float* slab_in) {
+            h2zero<NT, MT>(net);
+            __syncthreads();
+            h2gemm(net, ring, ws, fc0seg(blk), fc1seg(blk), planes, lane, 2);
+            __syncthreads();
+            h2epilogue<false>(net, fc0_bias(blk), planes, wave, lane);
+            if (slab_in) slab_load<NT, MT>(net, slab_in);
+            __syncthreads();
+            h2gemm(h, ring, ws, fc1seg(blk), after, planes, lane, 4);
+            if (slab_in) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) h[nt][mt][r] = net[nt][mt][r] + h[nt][mt][r];
+            }
+        };
+        for (int v = 0; v < a.NS; ++v) {
+            const H2Seg after_view = v + 1 < a.NS ? s_in : (nvb < nb ? fc0seg(nvb) : s_in);
+            __syncthreads();
+            h2prologue(a, v, tile, planes, tap_tab, tid);
+            h2zero<NT, MT>(h);
+            __syncthreads();
+            h2gemm(h, ring, ws, s_in, fc0seg(0), planes, lane, 1);
+            for (int blk = 0; blk < nvb; ++blk) {
+                const bool last = blk == nvb - 1;
+                {
+                    // h += interp(lin_z[blk](latent map)): the block's 512 projected channels, staged in fp32 (see h2epilogue)
+                    GatherTaps<C, 1> g;
+                    gather_setup<C>(g, a.zp + (size_t)v * a.Hl * a.Wl * a.zp_stride + blk * HID, tap_tab, wave, lane);
+#ifndef PNY_H2_LATEISSUE
+                    gather_issue<C, 0>(g, 0, wave);
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                    __syncthreads();  // every wave is done reading the planes (previous GEMM)
+#ifdef PNY_H2_LATEISSUE
+                    gather_issue<C, 0>(g, 0, wave);
+#endif
+#ifdef PNY_H2_DOUBLEX
+                    __builtin_amdgcn_s_sleep(4);
+                    __syncthreads();
+#endif
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        h2gather_commit(g, planes, c, wave, lane);
+                        if (c < 3) gather_issue<C, 0>(g, (c + 1) * GCH, wave);
+                    }
+                }
+                __syncthreads();  // projection visible
+                h2epilogue<true>(h, entry_bias(blk), planes, wave, lane);
+                block_tail(blk, last ? after_view : fc0seg(blk + 1), (last && v > 0) ? slab : nullptr);
+            }
+            if (a.NS > 1) {
+                if (v + 1 < a.NS) {
+                    slab_store<NT, MT>(h, slab);
+                } else {
+                    const float ns = (float)a.NS;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) h[nt][mt][r] = h[nt][mt][r] / ns;
+                }
+            }
+        }
+        for (int blk = nvb; blk < nb; ++blk) {
+            __syncthreads();
+            h2epilogue<false>(h, entry_bias(blk), planes, wave, lane);
+            block_tail(blk, blk + 1 < nb ? fc0seg(blk + 1) : s_in, nullptr);
+        }
+        // out = lin_out(relu(h + b_fc1[last])) (reference resnetfc.py:185) + output head (models.py:312-317)
+        __syncthreads();
+        h2epilogue<false>(h, entry_bias(nb), planes, wave, lane);
+        __syncthreads();
+        for (int idx = tid; idx < a.d_out * TM; idx += THREADS) {
+            const int o = idx / TM, m = idx % TM;
+            const float4* wrow = reinterpret_cast<const float4*>(a.w.w_out + (size_t)o * HID);
+            float sum = 0.f;
+#pragma unroll 4
+            for (int kg = 0; kg < HID / 8; ++kg) {
+                const h8 x0 = *reinterpret_cast<const h8*>(planes + kg * (2 * ROW_BYTES) + m * 16);
+                const h8 x1 = *reinterpret_cast<const h8*>(planes + kg * (2 * ROW_BYTES) + ROW_BYTES + m * 16);
+                const float4 wa = wrow[2 * kg], wb = wrow[2 * kg + 1];
+                sum += ((float)x0[0] + (float)x1[0]) * wa.x;
+                sum += ((float)x0[1] + (float)x1[1]) * wa.y;
+                sum += ((float)x0[2] + (float)x1[2]) * wa.z;
+                sum += ((float)x0[3] + (float)x1[3]) * wa.w;
+                sum += ((float)x0[4] + (float)x1[4]) * wb.x;
+                sum += ((float)x0[5] + (float)x1[5]) * wb.y;
+                sum += ((float)x0[6] + (float)x1[6]) * wb.z;
+                sum += ((float)x0[7] + (float)x1[7]) * wb.w;
+            }
+            sum += a.w.b_out[o];
+            if (!a.yolo) {
+                if (o < 3)
+                    sum = 1.0f / (1.0f + expf(-sum));
+                else if (o == 3)
+                    sum = fmaxf(sum, 0.f);
+            }
+            const long long s = tile * TM + m;
+            if (s < a.n_points) a.out[s * a.d_out + o] = sum;
+        }
+    }
+}
+
+bool mlp_h2_supports(int n_blocks, int combine_layer) { return n_blocks <= h2::MAX_NB && combine_layer >= 1; }
+
+void launch_mlp_h2(const MlpArgs& a, int grid, hipStream_t st) {
+    static bool attr_set[64] = {};
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    dev_ &= 63;
+    if (!attr_set[dev_]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pny_mlp_h2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  h2::lds_bytes(h2::MAX_NB));
+        attr_set[dev_] = true;
+    }
+    hipLaunchKernelGGL(pny_mlp_h2_kernel, dim3(grid), dim3(h2::THREADS), h2::lds_bytes(a.n_blocks), st, a);
+}
+
+}  // namespace pny

@@ -85,13 +85,17 @@ struct MlpArgs {
     // training: activation stash written by the STASH instantiation (launch_mlp_stash); null otherwise
     float* stash_x;
     StashLayout lay;
+    // split-f16 operand images of lin_in / fc_0 / fc_1 (mlp_h2.hip; api.hip pack_layer_h2), inside the same blob as `w`
+    const float* h2_in;
+    const float* h2_fc0[MAX_BLOCKS];
+    const float* h2_fc1[MAX_BLOCKS];
     // Source-view cameras travel in the kernel-argument segment (NS entries used; 64 B each): a launch carries its own
     // copy, so pny_scene_set_cameras touches no device memory (no copy, no synchronisation, no stream to order against)
     Cam cams[MAX_VIEWS];
 };
 
 // ---- device-side weight repack (pack.hip): the packed operand layouts rebuilt from the live parameter tensors
-enum { PACK_A = 0, PACK_AT = 1, PACK_NT = 2, PACK_COPY = 3, PACK_ADD2 = 4 };
+enum { PACK_A = 0, PACK_AT = 1, PACK_NT = 2, PACK_COPY = 3, PACK_ADD2 = 4, PACK_H2 = 5 };
 struct PackJob {
     const float* src;
     const float* src2;
@@ -179,6 +183,8 @@ enum { MLP_8x64 = 0, MLP_16x64 = 1, MLP_8x32 = 2 };  // kernel shapes (mlp.hip C
 int mlp_pick_variant(long long n_points);           // shape for a launch of n_points samples
 void launch_mlp(const MlpArgs& a, int variant, int grid, hipStream_t st);
 void launch_mlp_stash(const MlpArgs& a, int grid, hipStream_t st);  // 8x64 shape, reference op order, writes a.stash_x
+bool mlp_h2_supports(int n_blocks, int combine_layer);
+void launch_mlp_h2(const MlpArgs& a, int grid, hipStream_t st);     // 8x64 shape, projected latent, split-f16 operands (mlp_h2.hip)
 int mlp_max_grid(int variant);      // resident workgroups = persistent grid size
 int mlp_tile_samples(int variant);  // samples per workgroup tile (32 or 64)
 size_t mlp_scratch_floats();

@@ -94,6 +94,8 @@ SIGNATURES = {
     "pny_tp_fp_fn": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double,
                                C.c_void_p, C.c_void_p]),
     "pny_scene_set_projection": (C.c_int, [C.c_void_p, C.c_int]),
+    "pny_scene_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
+    "pny_scene_last_precision": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "pny_scene_project": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pny_scene_last_mlp_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                            C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -114,8 +116,9 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 6
+ABI_VERSION = 7
 PROJECTION = {"off": 0, "on": 1, "auto": 2}
+PRECISION = {"f32": 0, "f16x2": 1, "auto": 2}
 
 
 class PnyError(RuntimeError):

@@ -235,6 +235,7 @@ class PixelNeRFNet(nn.Module):
         self._dev_bound = False
         self._timing = False
         self._projection = None  # None = library default (auto, or env PNYOLO_PROJECTION)
+        self._precision = None   # None = library default (auto, or env PNYOLO_MLP_PRECISION)
 
     # ---------------------------------------------------------------- native plumbing
     def _device(self):
@@ -329,6 +330,8 @@ class PixelNeRFNet(nn.Module):
             check(L.pny_scene_enable_timing(s, int(self._timing)))
             if self._projection is not None:
                 check(L.pny_scene_set_projection(s, _lib.PROJECTION[self._projection]))
+            if self._precision is not None:
+                check(L.pny_scene_set_precision(s, _lib.PRECISION[self._precision]))
             self._h_scenes.append(s)
         return self._h_scenes[i]
 
@@ -348,6 +351,23 @@ class PixelNeRFNet(nn.Module):
         for s in self._h_scenes:
             check(_lib.load().pny_scene_set_projection(s, _lib.PROJECTION[mode]))
         return self
+
+    def set_matrix_precision(self, mode):
+        """'auto' | 'f32' | 'f16x2' (include/pnyolo.h pny_scene_set_precision): the matrix arithmetic of projected
+        launches -- fp32 MFMA, or fp32 operands split into two f16 planes on the f16 matrix cores (same measured
+        error, 5.3x the matrix rate).  Launches without projection always run fp32."""
+        if mode not in _lib.PRECISION:
+            raise ValueError("matrix precision must be one of %s" % sorted(_lib.PRECISION))
+        self._precision = mode
+        for s in self._h_scenes:
+            check(_lib.load().pny_scene_set_precision(s, _lib.PRECISION[mode]))
+        return self
+
+    def last_launch_f16x2(self, scene=0):
+        """True when the last MLP launch of scene `scene` ran the f16x2 kernel."""
+        v = C.c_int(0)
+        check(_lib.load().pny_scene_last_precision(self._scene(scene), C.byref(v)))
+        return bool(v.value)
 
     def project_latent(self):
         """Compute the projected maps of the encoded scenes now (otherwise done lazily by the first

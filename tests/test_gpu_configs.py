@@ -29,10 +29,14 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-@pytest.fixture(params=["off", "on"])
+@pytest.fixture(params=["off", "on", "on+f16x2"])
 def projection(request, monkeypatch):
-    monkeypatch.setenv("PNYOLO_PROJECTION", request.param)
-    return request.param
+    """Scene defaults read at pny_scene_create: reference operation order / projected latent on the fp32 matrix path /
+    projected latent on the split-f16 matrix path (every projected launch).  Returns "off" or "on"."""
+    mode, _, prec = request.param.partition("+")
+    monkeypatch.setenv("PNYOLO_PROJECTION", mode)
+    monkeypatch.setenv("PNYOLO_MLP_PRECISION", prec or "f32")
+    return mode
 
 
 def c3_conf():

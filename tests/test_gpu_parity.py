@@ -36,11 +36,15 @@ DEV = "cuda:0"
 TOL = 1e-4
 
 
-@pytest.fixture(params=["off", "on"])
+@pytest.fixture(params=["off", "on", "on+f16x2"])
 def projection(request, monkeypatch):
-    """Library-wide default of new scenes (read at pny_scene_create)."""
-    monkeypatch.setenv("PNYOLO_PROJECTION", request.param)
-    return request.param
+    """Library-wide defaults of new scenes (read at pny_scene_create): reference operation order / projected latent on
+    the fp32 matrix path / projected latent on the split-f16 matrix path (every projected launch).  Returns "off" or
+    "on"; the same golden vectors and the same 1e-4 bar hold for all three."""
+    mode, _, prec = request.param.partition("+")
+    monkeypatch.setenv("PNYOLO_PROJECTION", mode)
+    monkeypatch.setenv("PNYOLO_MLP_PRECISION", prec or "f32")
+    return mode
 
 
 def dt(x):
@@ -550,6 +554,30 @@ def test_projection_cache_follows_latent_and_weights(golden):
         net.project_latent()          # explicit projection while switched off is an error, not a no-op
     with pytest.raises(ValueError):
         net.set_latent_projection("sometimes")
+
+
+def test_f16x2_stress_deterministic_and_close_to_f32(golden, monkeypatch):
+    """The split-f16 matrix path (include/pnyolo.h pny_scene_set_precision) on a launch that fills every CU several
+    times: bit-identical from run to run, and within 2e-5 of the fp32 matrix path on the same points (both are held to
+    1e-4 of the reference by the goldens; this bounds their mutual distance on 200k points the goldens do not cover).
+    Guards the packed-f32 hazard recorded in csrc/Makefile (mlp_h2.o)."""
+    g = golden("nerf_c2")
+    monkeypatch.setenv("PNYOLO_PROJECTION", "on")
+    rng = np.random.default_rng(5)
+    n = 200_000
+    idx = rng.integers(0, g["probe_xyz"].shape[0], n)
+    jitter = rng.normal(0.0, 0.02, (n, 3)).astype(np.float32)
+    xyz, vd = dt(g["probe_xyz"][idx] + jitter)[None], dt(g["probe_viewdirs"][idx])[None]
+    outs = {}
+    for prec in ("f32", "f16x2"):
+        monkeypatch.setenv("PNYOLO_MLP_PRECISION", prec)
+        net = nerf_net(g, 7)
+        with torch.no_grad():
+            runs = [net(xyz, coarse=False, viewdirs=vd)[0] for _ in range(3)]
+        assert net.last_launch_f16x2() == (prec == "f16x2")
+        assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2]), prec
+        outs[prec] = runs[0]
+    assert float((outs["f32"] - outs["f16x2"]).abs().max()) < 2e-5
 
 
 def test_projection_error_is_fp32_conditioning(golden, monkeypatch):
