@@ -27,12 +27,17 @@ this is the conservative reading).  c2/c3/c5: every rank renders its own frame; 
 max-over-ranks time.  c4: value = the frame's rays / max-over-ranks time.
 
 One JSON line on rank 0 with the contract fields plus
-  roofline      dominant kernel = pny_mlp_kernel.  `achieved` = the GEMM FLOPs the launched kernel variant EXECUTES
-                (2/MAC, unpadded; with the projected latent lin_z has left the kernel: 1.8668 GFLOP/ray at C2 instead
-                of SURVEY.md 8d's 2.6218) / its HIP-event time measured inside libpnyolo on the launch stream;
-                peak = 157.3 TFLOP/s exact-fp32 MFMA; `frac` = achieved / peak is therefore an executed-FLOP
-                UTILISATION.  `frac_survey_formula` = rays/s x SURVEY.md 8d's FLOP/ray / (peak x GPUs), the
-                formula of the scope table: it exceeds `frac` (and can exceed 1) because the projection removes work.
+  roofline      dominant kernel = the fused MLP kernel.  `achieved` = the fp32 GEMM FLOPs the launched kernel variant
+                EXECUTES (2/MAC, unpadded; with the projected latent lin_z has left the kernel: 1.8668 GFLOP/ray at C2
+                instead of SURVEY.md 8d's 2.6218) / its HIP-event time measured inside libpnyolo on the launch stream.
+                Default matrix path (pny_mlp_h2_kernel): every fp32 operand is split into two f16 planes and a product is
+                three v_mfma_f32_32x32x16_f16 with fp32 accumulation (same measured error as the fp32 MFMA; same goldens,
+                same 1e-4 bar): the bound is the f16 matrix pipe at three issued MFMA FLOPs per fp32 GEMM FLOP,
+                peak = 2516.8 / 3 = 838.9 TFLOP/s of fp32 GEMM work; `frac` = achieved / peak = the fraction of the
+                f16 matrix pipe's time the kernel keeps it busy.  With --precision f32 (pny_mlp_kernel,
+                v_mfma_f32_32x32x2_f32) peak = 157.3 TFLOP/s.  `frac_survey_formula` = rays/s x SURVEY.md 8d's FLOP/ray
+                / (peak x GPUs), the formula of the scope table (it counts the lin_z work the projection removed).
+  fp32_matrix_path           (N = 1) the same frame on the exact-fp32 MFMA kernel: rays/s, ms per launch, frac of 157.3.
   roofline_reference_order   (N = 1) the same frame timed with `--projection off`, i.e. the reference's operation
                 order where executed FLOPs = SURVEY.md 8d's count: achieved / frac / ms per launch / rays per s.
   cpu_baseline  the oracle (oracle/pnyolo_oracle.py, a port) timed on the host cores on a bounded ray subset.
@@ -52,6 +57,8 @@ METRIC = "rays/sec (whole node), 64 samples/ray, 3-view 128×128 render"
 NS = 3
 FOCAL128, Z_NEAR, Z_FAR = 131.25, 0.8, 1.8
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F16_MFMA_TFLOPS = 16 * 157.3  # same table: the f32 matrix rate is 1/16 of the dense BF16/F16 rate (~2.5 PF)
+PEAK_F16X2_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3  # split operands: x1 w1 + x2 w1 + x1 w2 = 3 issued MFMA FLOPs per fp32 FLOP
 
 # name -> (image side, d_latent, latent side, n_coarse, n_fine, n_fine_depth, scaling, description)
 WORKLOADS = {
@@ -210,6 +217,9 @@ def main():
     ap.add_argument("--cpu-rays", type=int, default=None, help="ray subset for the CPU baseline (0 = skip)")
     ap.add_argument("--projection", choices=["auto", "on", "off"], default="auto",
                     help="latent projection mode of the fused MLP (off = the reference's operation order)")
+    ap.add_argument("--precision", choices=["auto", "f32", "f16x2"], default="auto",
+                    help="matrix arithmetic of projected launches (include/pnyolo.h pny_scene_set_precision)")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the --precision f32 leg of the N=1 line")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2",
                     help="c2 = BASELINE.json configs[1] (default, the bench line); c3/c4/c5 = configs[2..4]")
     ap.add_argument("--no-reference-order", action="store_true", help="skip the --projection off leg of the N=1 line")
@@ -280,6 +290,7 @@ def main():
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
     net = net.to(dev)
     net.set_latent_projection(args.projection)
+    net.set_matrix_precision(args.precision)
     src, _ = synth.scene_cameras(NS, radius=1.3 + 0.02 * scene_id)
     # weak-scaling workloads: every rank renders its own target view; c4: ONE view for all ranks
     tgt = synth.pose_spherical(120.0 + (0.0 if wl == "c4" else 10.0 * rank), -20.0, 1.3)
@@ -375,7 +386,7 @@ def main():
         net.enable_kernel_timing(True)
         fence()
         t0 = time.perf_counter()
-        acc = dict(ms=0.0, flops=0.0, ref=0.0, launches=0, projected=False)
+        acc = dict(ms=0.0, flops=0.0, ref=0.0, launches=0, projected=False, f16x2=False)
         for _ in range(steps):
             rgb, depth = step()
             # HIP-event times of this step's MLP launches (recorded on the launch stream inside
@@ -386,6 +397,7 @@ def main():
             acc["ms"] += st["kernel_ms"]
             acc["launches"] += st["launches"]
             acc["projected"] = acc["projected"] or st["projected"]
+            acc["f16x2"] = acc["f16x2"] or net.last_launch_f16x2()
         fence()
         elapsed = time.perf_counter() - t0
         net.enable_kernel_timing(False)
@@ -407,7 +419,7 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "mlp_traffic.json")) as fh:
             tj = json.load(fh)
-        if bool(tj.get("projected_latent")) == bool(projected) and wl == "c2":
+        if bool(tj.get("projected_latent")) == bool(projected) and bool(tj.get("f16x2")) == bool(acc["f16x2"]) and wl == "c2":
             traffic, traffic_note = tj["bytes_per_launch"], "%s: %s" % (tj["tag"], tj["method"])
     except (OSError, ValueError, KeyError):
         pass
@@ -417,11 +429,19 @@ def main():
 
     def roof(a, rays_per_s, n_gpus):
         ach = a["flops"] / (a["ms"] * 1e-3) / 1e12 if a["ms"] > 0 else None
+        peak = PEAK_F16X2_TFLOPS if a["f16x2"] else PEAK_F32_MFMA_TFLOPS
+        extra = {}
+        if a["f16x2"]:
+            extra = {"matrix_path": "f16x2: fp32 operands as two f16 planes, 3 x v_mfma_f32_32x32x16_f16 per product, fp32 "
+                                    "accumulate (error = the fp32 MFMA's, tools/ubench/split_f16_check.hip)",
+                     "peak_is": "dense f16 MFMA peak %.1f / 3 issued MFMA FLOPs per fp32 GEMM FLOP" % PEAK_F16_MFMA_TFLOPS,
+                     "issued_f16_tflops": 3 * ach if ach else None,
+                     "x_fp32_mfma_peak": (ach / PEAK_F32_MFMA_TFLOPS) if ach else None}
         return {
-            "bound": "mfma", "kernel": "pny_mlp_kernel", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": (ach / PEAK_F32_MFMA_TFLOPS) if ach else None,
+            "bound": "mfma", "kernel": "pny_mlp_h2_kernel" if a["f16x2"] else "pny_mlp_kernel", "achieved": ach, "peak": peak,
+            "unit": "TFLOP/s", "frac": (ach / peak) if ach else None,
             "frac_is": "executed-FLOP utilisation of this rank's MLP launches (HIP events on the launch stream)",
-            "frac_survey_formula": rays_per_s * flop_per_ray(wl, False) / (PEAK_F32_MFMA_TFLOPS * 1e12 * n_gpus),
+            "frac_survey_formula": rays_per_s * flop_per_ray(wl, False) / (peak * 1e12 * n_gpus), **extra,
             "launches": a["launches"], "avg_launch_ms": (a["ms"] / a["launches"]) if a["launches"] else None,
             "flops_per_launch": (a["flops"] / a["launches"]) if a["launches"] else None,
             "projected_latent": a["projected"],
@@ -433,7 +453,8 @@ def main():
     out = {
         "metric": METRIC, "value": value, "unit": "rays/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+        "dtype": "f32 (matrix products on f16x2 split operands, fp32 accumulate)" if acc["f16x2"] else "f32", "data": "synthetic",
         "config": dict(describe(wl)["config"], n_views=NS, n_coarse=KC, n_fine=KF, n_fine_depth=KFD,
                        global_rays_per_step=rays_per_step, rays_per_step_this_rank=n_rays,
                        parallelism={"c4": "one frame's rays sharded over %d ranks (per-rank ray generation), 1 process/GPU, "
@@ -446,6 +467,19 @@ def main():
     }
     if args.rehearse_one_gpu:
         out["rehearsal"] = "ranks share ONE GPU, gloo transport: mechanics check, not a measurement"
+
+    if world == 1 and acc["f16x2"] and not args.no_fp32_leg:
+        # the same frame on the exact-fp32 MFMA kernel (v_mfma_f32_32x32x2_f32), projection unchanged
+        net.set_matrix_precision("f32")
+        step()
+        k_f32 = max(2, min(3, args.steps))
+        e3, a3, _, _ = timed(k_f32)
+        r3 = roof(a3, rays_per_step * k_f32 / e3, 1)
+        out["fp32_matrix_path"] = {
+            "rays_per_s": rays_per_step * k_f32 / e3, "steps": k_f32, "kernel": r3["kernel"], "achieved": r3["achieved"],
+            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": r3["frac"], "ms_per_launch": r3["avg_launch_ms"],
+            "note": "--precision f32: not the bench value"}
+        net.set_matrix_precision(args.precision)
 
     if world == 1 and args.projection != "off" and not args.no_reference_order:
         # the same frame in the reference's operation order (lin_z per sample): executed FLOPs = SURVEY.md 8d's count

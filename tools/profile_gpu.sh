@@ -11,6 +11,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH >
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $BENCH > "$OUT/pmc_fetch.log" 2>&1 || { echo "pmc fetch failed"; tail -5 "$OUT/pmc_fetch.log"; exit 1; }
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- $BENCH > "$OUT/pmc_write.log" 2>&1 || { echo "pmc write failed"; tail -5 "$OUT/pmc_write.log"; exit 1; }
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_sq" -- $BENCH > "$OUT/pmc_sq.log" 2>&1 || { echo "pmc sq failed"; tail -5 "$OUT/pmc_sq.log"; }
-rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F32 TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/pmc_lds" -- $BENCH > "$OUT/pmc_lds.log" 2>&1 || { echo "pmc lds failed"; tail -5 "$OUT/pmc_lds.log"; }
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F16 TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/pmc_lds" -- $BENCH > "$OUT/pmc_lds.log" 2>&1 || { echo "pmc lds failed"; tail -5 "$OUT/pmc_lds.log"; }
 find "$OUT" -name "*.csv" | head -30
 du -sh "$OUT"

@@ -23,7 +23,7 @@ def frame_rows(pattern):
     """MLP-kernel rows of the full-frame launches only: bench.py's one-time setup renders 256 and 4096 rays before
     the steps (code-object load), which must not dilute per-launch means.  Full-frame = at least half as long as the
     longest MLP dispatch of the pass."""
-    mlp = [r for r in rows(pattern) if "pny_mlp_kernel" in r.get("Kernel_Name", "")]
+    mlp = [r for r in rows(pattern) if "pny_mlp_kernel" in r.get("Kernel_Name", "") or "pny_mlp_h2_kernel" in r.get("Kernel_Name", "")]
     if not mlp:
         return []
     longest = max(dur_ms(r) for r in mlp)
@@ -37,7 +37,7 @@ def main(tag):
     agg = defaultdict(lambda: [0, 0.0, 1e30, 0.0])
     trace_pat = os.path.join(src, "trace", "**", "*kernel_trace.csv")
     frame = frame_rows(trace_pat)
-    for r in list(rows(trace_pat)) + [dict(r, Kernel_Name="pny_mlp_kernel, FULL-FRAME launches only (the bench steps)") for r in frame]:
+    for r in list(rows(trace_pat)) + [dict(r, Kernel_Name=r["Kernel_Name"].split("(")[0].split("<")[0] + ", FULL-FRAME launches only (the bench steps)") for r in frame]:
         name = r["Kernel_Name"].split("(")[0]
         dur = dur_ms(r)
         a = agg[name]
@@ -81,7 +81,8 @@ def main(tag):
                 names.add(r["Kernel_Name"].split("(")[0])
         per[cname] = tot / cnt if cnt else None
     if per["FETCH_SIZE"] is not None and per["WRITE_SIZE"] is not None:
-        traffic = {"tag": tag, "kernels": sorted(names), "projected_latent": any(", true>" in n for n in names),
+        traffic = {"tag": tag, "kernels": sorted(names), "projected_latent": any(", true>" in n or "pny_mlp_h2_kernel" in n for n in names),
+                   "f16x2": any("pny_mlp_h2_kernel" in n for n in names),
                    "fetch_kb_per_launch": per["FETCH_SIZE"], "write_kb_per_launch": per["WRITE_SIZE"],
                    "bytes_per_launch": (2.0 * per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024.0,
                    "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, mean over the "
