@@ -24,6 +24,7 @@
 //     152 of the CU's 160 KiB in use): no bias registers, no global loads between a barrier and a GEMM.  (mean over views of (h_v + b) = mean(h_v) + b, so the last per-view bias may follow the mean.)
 #include <cstdlib>
 #include <cstring>
+#include <cstdio>
 #include <vector>
 
 #include "mlp_core.h"
@@ -35,7 +36,7 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 namespace h2 {
 #ifndef PNY_H2_WD
-#define PNY_H2_WD 4
+#define PNY_H2_WD 2  // measured: 4 is 7 % faster inside the GEMMs, but its 32 more ring registers spill in the gather phase (-17 % overall)
 #endif
 constexpr int NT = 2, MT = 2, TM = 64, THREADS = 512, WD = PNY_H2_WD;  // WD = ring depth in 16-k steps
 constexpr int ROW_BYTES = TM * 16;          // one plane of one row (8 features x 64 samples x f16)
@@ -45,6 +46,30 @@ constexpr int MAX_NB = 6;                      // bias table: (1 + 2 n_blocks) x
 __host__ __device__ constexpr int lds_bytes(int n_blocks) { return ACT_BYTES + TAP_BYTES + (1 + 2 * n_blocks) * HID * 4; }
 using C = Cfg<2, 2>;
 }  // namespace h2
+
+// Diagnostic build only (-DPNY_H2_STAMP): s_memtime brackets around the phases of a tile, summed per wave and printed by
+// launch_mlp_h2.  No stamp executes in the product build.
+#ifdef PNY_H2_STAMP
+enum { HS_TOTAL = 0, HS_GEMM, HS_GATHER_WAIT, HS_GATHER, HS_EPI_WAIT, HS_EPI, HS_PROLOGUE, HS_LINOUT, HS_SLAB, HS_N };
+__device__ unsigned long long* g_h2_stamp_buf;
+__device__ __forceinline__ unsigned long long h2now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define HS_T0() hs_t_ = h2now()
+#define HS_LAP(cat)                         \
+    {                                       \
+        const unsigned long long n_ = h2now(); \
+        hs_acc[cat] += n_ - hs_t_;          \
+        hs_t_ = n_;                         \
+    }
+#else
+#define HS_T0()
+#define HS_LAP(cat)
+#endif
 
 struct H2Seg {
     unsigned off;  // byte offset of fragment (step 0, this wave's first n-tile, plane 0) in the weight blob
@@ -82,8 +107,12 @@ __device__ __forceinline__ void h2ring_fill(H2Ring& r, const WStream& ws, const 
 // acc += W_slice . act over segment `cur` (its 16-k steps a multiple of the ring depth); leaves the ring holding the first
 // WD - 1 steps of `next`.  Per step and accumulator tile: x1 w1 + x2 w1 + x1 w2.  Static ring slots as in gemm_run
 // (mlp_core.h): slot d is consumed by step j + d while slot d - 1 is refilled with step j + d - 1 + WD.
+struct NoSide {
+    __device__ __forceinline__ void operator()() const {}
+};
+template <class Side = NoSide>
 __device__ __forceinline__ void h2gemm(f32x16 (&acc)[h2::NT][h2::MT], H2Ring& r, const WStream& ws, const H2Seg& cur,
-                                       const H2Seg& next, const char* planes, int lane, int which = 0) {
+                                       const H2Seg& next, const char* planes, int lane, Side side = Side()) {
     using namespace h2;
     const int m0 = lane & 31, hh = lane >> 5;
     const char* bp = planes + hh * (2 * ROW_BYTES) + m0 * 16;   // row 2 j + hh, plane 0, sample m0
@@ -94,6 +123,9 @@ __device__ __forceinline__ void h2gemm(f32x16 (&acc)[h2::NT][h2::MT], H2Ring& r,
 #pragma unroll
         for (int p = 0; p < 2; ++p) B[0][mt][p] = *reinterpret_cast<const h8*>(bp + p * ROW_BYTES + 32 * mt * 16);
     for (int j = 0; j < jn; j += WD) {
+        // `side` (loads whose results are needed after this GEMM: the first chunk of the next block's gather) is issued
+        // from INSIDE the loop: placed in front of it the compiler sinks the loads behind the loop, to their first use
+        if (j == WD) side();
 #pragma unroll
         for (int d = 0; d < WD; ++d) {
             const int jd = j + d;
@@ -166,27 +198,36 @@ __device__ __forceinline__ void h2gemm(f32x16 (&acc)[h2::NT][h2::MT], H2Ring& r,
                 for (int p = 0; p < 2; ++p) asm volatile("" ::"v"(B[d & 1][mt][p]));
         }
     }
-#ifdef PNY_H2_SLEEP
-    __builtin_amdgcn_s_sleep(PNY_H2_SLEEP);
-#endif
-#ifdef PNY_H2_PARANOID
-    if (PNY_H2_PARANOID & which) __syncthreads();
-#endif
-#ifdef PNY_H2_WAIT
-    if (PNY_H2_WAIT & which) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
 }
 
 // split 4 fp32 values into the two f16 planes (round to nearest)
+// Two values per call: x1 pair = v_cvt_pk_f16_f32 (round to nearest even), residuals x - f32(x1) by v_fma_mix_f32 reading the
+// f16 halves in place (exact, like the subtraction), x2 pair = v_cvt_pk_f16_f32 of the residuals: 4 VALU instructions
+// per pair where the compiler's form of the C expression takes 8 (scalar convert, convert back, subtract, two packs).
+__device__ __forceinline__ void split2(float a, float b, unsigned& p0, unsigned& p1) {
+#ifdef PNY_H2_PLAIN_SPLIT
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    h2v q0, q1;
+    q0[0] = (_Float16)a;
+    q0[1] = (_Float16)b;
+    q1[0] = (_Float16)(a - (float)q0[0]);
+    q1[1] = (_Float16)(b - (float)q0[1]);
+    p0 = __builtin_bit_cast(unsigned, q0);
+    p1 = __builtin_bit_cast(unsigned, q1);
+#else
+    float ra, rb;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p0) : "v"(a), "v"(b));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(p0), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(p0), "v"(b));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p1) : "v"(ra), "v"(rb));
+#endif
+}
 __device__ __forceinline__ void split4(float a, float b, float c, float d, h4& p0, h4& p1) {
-    p0[0] = (_Float16)a;
-    p0[1] = (_Float16)b;
-    p0[2] = (_Float16)c;
-    p0[3] = (_Float16)d;
-    p1[0] = (_Float16)(a - (float)p0[0]);
-    p1[1] = (_Float16)(b - (float)p0[1]);
-    p1[2] = (_Float16)(c - (float)p0[2]);
-    p1[3] = (_Float16)(d - (float)p0[3]);
+    uint2 u0, u1;
+    split2(a, b, u0.x, u1.x);
+    split2(c, d, u0.y, u1.y);
+    p0 = __builtin_bit_cast(h4, u0);
+    p1 = __builtin_bit_cast(h4, u1);
 }
 
 // The 8-byte slot of feature quad (row, half) = (feature / 8, (feature / 4) & 1) of sample m in plane p is at byte
@@ -202,23 +243,36 @@ __device__ __forceinline__ void h2epilogue(f32x16 (&acc)[h2::NT][h2::MT], const 
     const float* bl = bias + 32 * NT * wave + 4 * hh;
     // accumulator quad (nt, q) of this lane = features 32 NT wave + 32 nt + 8 q + 4 hh + 0..3: row 4 NT wave + 4 nt + q, half hh
     char* base = planes + (4 * NT * wave) * (2 * ROW_BYTES) + m0 * 16 + 8 * hh;
+    // the LDS reads of a (nt, mt) tile -- bias quads, staged projection -- are issued together ahead of its arithmetic
+    // (left to itself the compiler reads, waits and converts quad by quad: 16 exposed LDS latencies per epilogue)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int nt = 0; nt < NT; ++nt) {
+        float4 b[4];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int q = 0; q < 4; ++q) b[q] = *reinterpret_cast<const float4*>(bl + 32 * nt + 8 * q);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            float2 za[4], zb[4];
+            if (ADDZ) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const char* s0 = base + (4 * nt + q) * (2 * ROW_BYTES) + 32 * mt * 16;
+                    za[q] = *reinterpret_cast<const float2*>(s0);
+                    zb[q] = *reinterpret_cast<const float2*>(s0 + ROW_BYTES);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 char* s0 = base + (4 * nt + q) * (2 * ROW_BYTES) + 32 * mt * 16;
                 char* s1 = s0 + ROW_BYTES;
-                const float4 b = *reinterpret_cast<const float4*>(bl + 32 * nt + 8 * q);
-                float x0 = acc[nt][mt][4 * q + 0] + b.x, x1 = acc[nt][mt][4 * q + 1] + b.y;
-                float x2 = acc[nt][mt][4 * q + 2] + b.z, x3 = acc[nt][mt][4 * q + 3] + b.w;
+                float x0 = acc[nt][mt][4 * q + 0] + b[q].x, x1 = acc[nt][mt][4 * q + 1] + b[q].y;
+                float x2 = acc[nt][mt][4 * q + 2] + b[q].z, x3 = acc[nt][mt][4 * q + 3] + b[q].w;
                 if (ADDZ) {
-                    const float2 za = *reinterpret_cast<const float2*>(s0), zb = *reinterpret_cast<const float2*>(s1);
-                    x0 += za.x;
-                    x1 += za.y;
-                    x2 += zb.x;
-                    x3 += zb.y;
+                    x0 += za[q].x;
+                    x1 += za[q].y;
+                    x2 += zb[q].x;
+                    x3 += zb[q].y;
                 }
                 acc[nt][mt][4 * q + 0] = x0;
                 acc[nt][mt][4 * q + 1] = x1;
@@ -229,6 +283,8 @@ __device__ __forceinline__ void h2epilogue(f32x16 (&acc)[h2::NT][h2::MT], const 
                 *reinterpret_cast<h4*>(s0) = p0;
                 *reinterpret_cast<h4*>(s1) = p1;
             }
+        }
+    }
 }
 
 template <int NT_, int MT_>
@@ -242,7 +298,8 @@ __device__ __forceinline__ void h2zero(f32x16 (&t)[NT_][MT_]) {
 }
 
 // gather_commit (mlp_core.h) for the staging layout above: chunk c covers feature quads [32 c, 32 c + 32)
-__device__ __forceinline__ void h2gather_commit(const GatherTaps<h2::C, 1>& g, char* planes, int chunk, int wave, int lane) {
+template <int B>
+__device__ __forceinline__ void h2gather_commit(const GatherTaps<h2::C, 2>& g, char* planes, int chunk, int wave, int lane) {
     using namespace h2;
     constexpr int NMB = GatherTaps<C>::NMB, QSTEP = GatherTaps<C>::QSTEP;
     const int m = (wave % NMB) * 8 + (lane & 7);
@@ -251,32 +308,12 @@ __device__ __forceinline__ void h2gather_commit(const GatherTaps<h2::C, 1>& g, c
 #pragma unroll
     for (int i = 0; i < GatherTaps<C>::QPW; ++i) {
         const int qb = wave / NMB + i * QSTEP;
-        const float4(&x)[4] = g.x[0][i];
+        const float4(&x)[4] = g.x[B][i];
         float2 lo, hi;
         lo.x = __builtin_fmaf(x[3].x, g.w[3], __builtin_fmaf(x[2].x, g.w[2], __builtin_fmaf(x[1].x, g.w[1], x[0].x * g.w[0])));
         lo.y = __builtin_fmaf(x[3].y, g.w[3], __builtin_fmaf(x[2].y, g.w[2], __builtin_fmaf(x[1].y, g.w[1], x[0].y * g.w[0])));
         hi.x = __builtin_fmaf(x[3].z, g.w[3], __builtin_fmaf(x[2].z, g.w[2], __builtin_fmaf(x[1].z, g.w[1], x[0].z * g.w[0])));
         hi.y = __builtin_fmaf(x[3].w, g.w[3], __builtin_fmaf(x[2].w, g.w[2], __builtin_fmaf(x[1].w, g.w[1], x[0].w * g.w[0])));
-#ifdef PNY_H2_NOGATHER
-#if PNY_H2_NOGATHER == 1
-        lo = make_float2(0.f, 0.f);
-        hi = make_float2(0.f, 0.f);
-#elif PNY_H2_NOGATHER == 2   // weights only (tap table)
-        lo = make_float2(g.w[0], g.w[1]);
-        hi = make_float2(g.w[2], g.w[3]);
-#elif PNY_H2_NOGATHER == 3   // data of tap 0 only
-        lo = make_float2(x[0].x, x[0].y);
-        hi = make_float2(x[0].z, x[0].w);
-#elif PNY_H2_NOGATHER >= 16   // only the chunks in the mask (PNY_H2_NOGATHER - 16)
-        if (!(((PNY_H2_NOGATHER - 16) >> chunk) & 1)) {
-            lo = make_float2(0.f, 0.f);
-            hi = make_float2(0.f, 0.f);
-        }
-#elif PNY_H2_NOGATHER == 4   // tap offsets only
-        lo = make_float2((float)(g.t[0] - g.t[1]) * 1e-6f, (float)(g.t[2] - g.t[3]) * 1e-6f);
-        hi = lo;
-#endif
-#endif
         char* s0 = base + (4 * qb) * (2 * ROW_BYTES);
         *reinterpret_cast<float2*>(s0) = lo;
         *reinterpret_cast<float2*>(s0 + ROW_BYTES) = hi;
@@ -357,14 +394,24 @@ __global__ __launch_bounds__(h2::THREADS, 2) void pny_mlp_h2_kernel(const MlpArg
     const int nvb = a.combine_layer < nb ? a.combine_layer : nb;   // >= 1 (the host only selects this kernel with a projection)
     const WStream ws = wstream(a, lane);
     const H2Seg s_in = h2seg(ws, a.h2_in, D_IN_PAD / 16, wave);
+#ifdef PNY_H2_EXP_FOOT   // timing only: every 512x512 layer streams block 0's fc_0 image (1 MiB footprint; wrong results)
+    auto fc0seg = [&](int b) { return h2seg(ws, a.h2_fc0[0], HID / 16, wave); };
+    auto fc1seg = [&](int b) { return h2seg(ws, a.h2_fc0[0], HID / 16, wave); };
+#else
     auto fc0seg = [&](int b) { return h2seg(ws, a.h2_fc0[b], HID / 16, wave); };
     auto fc1seg = [&](int b) { return h2seg(ws, a.h2_fc1[b], HID / 16, wave); };
+#endif
     // bias applied at the entry of block b (b = n_blocks: before lin_out): b_in, or the previous block's b_fc1 -- the host
     // (api.hip pack_mlp) has folded the block's lin_z bias into either
     auto entry_bias = [&](int b) { return bias_tab + (b == 0 ? 0 : 2 * b) * HID; };
     auto fc0_bias = [&](int b) { return bias_tab + (1 + 2 * b) * HID; };
     H2Ring ring;
     h2ring_fill(ring, ws, s_in);
+#ifdef PNY_H2_STAMP
+    unsigned long long hs_acc[HS_N], hs_t_ = 0;
+    for (int i = 0; i < HS_N; ++i) hs_acc[i] = 0;
+    const unsigned long long hs_start = h2now();
+#endif
     for (int i = tid; i < (1 + 2 * nb) * HID; i += THREADS) {
         const int vec = i / HID, f = i % HID;
         const float* src = vec == 0 ? a.w.b_in : ((vec & 1) ? a.w.b_fc0[(vec - 1) >> 1] : a.w.b_fc1[(vec - 2) >> 1]);
@@ -381,80 +428,123 @@ __global__ __launch_bounds__(h2::THREADS, 2) void pny_mlp_h2_kernel(const MlpArg
     for (long long tile = t_first; tile < t_last; tile += t_step) {
         f32x16 h[NT][MT];
         f32x16 net[NT][MT];
-        // one residual block from "planes hold relu(h_in)" on: net = fc_0(.), h += fc_1(relu(net + b_fc0))
-        auto block_tail = [&](int blk, const H2Seg& after, const float* slab_in) {
+        GatherTaps<C, 2> g;   // taps of the current view; two chunks of projected channels in flight
+        // one residual block from "planes hold relu(h_in)" on: net = fc_0(.), h += fc_1(relu(net + b_fc0)).  `next_c0` >= 0:
+        // the first chunk of the NEXT block's projection (channel offset next_c0) is fetched into gather buffer 0
+        // underneath the fc_1 GEMM -- `net` is dead there, its registers hold the chunk.
+        auto block_tail = [&](int blk, const H2Seg& after, const float* slab_in, int next_c0) {
+            HS_T0();
             h2zero<NT, MT>(net);
             __syncthreads();
-            h2gemm(net, ring, ws, fc0seg(blk), fc1seg(blk), planes, lane, 2);
+            HS_LAP(HS_EPI_WAIT);
+            h2gemm(net, ring, ws, fc0seg(blk), fc1seg(blk), planes, lane);
+            HS_LAP(HS_GEMM);
             __syncthreads();
+            HS_LAP(HS_EPI_WAIT);
             h2epilogue<false>(net, fc0_bias(blk), planes, wave, lane);
-            if (slab_in) slab_load<NT, MT>(net, slab_in);
-            __syncthreads();
-            h2gemm(h, ring, ws, fc1seg(blk), after, planes, lane, 4);
+            // three exclusive continuations (the running sum of the other views and the prefetched chunk both want the
+            // registers of `net`: written as one if / else chain so that the allocator never has to provide for both)
             if (slab_in) {
+                slab_load<NT, MT>(net, slab_in);
+                HS_LAP(HS_EPI);
+                __syncthreads();
+                HS_LAP(HS_EPI_WAIT);
+                h2gemm(h, ring, ws, fc1seg(blk), after, planes, lane);
+                HS_LAP(HS_GEMM);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) h[nt][mt][r] = net[nt][mt][r] + h[nt][mt][r];
+            } else if (next_c0 >= 0) {
+                HS_LAP(HS_EPI);
+                __syncthreads();
+                HS_LAP(HS_EPI_WAIT);
+                h2gemm(h, ring, ws, fc1seg(blk), after, planes, lane, [&]() { gather_issue<C, 0>(g, next_c0, wave); });
+                HS_LAP(HS_GEMM);
+            } else {
+                HS_LAP(HS_EPI);
+                __syncthreads();
+                HS_LAP(HS_EPI_WAIT);
+                h2gemm(h, ring, ws, fc1seg(blk), after, planes, lane);
+                HS_LAP(HS_GEMM);
             }
         };
         for (int v = 0; v < a.NS; ++v) {
             const H2Seg after_view = v + 1 < a.NS ? s_in : (nvb < nb ? fc0seg(nvb) : s_in);
+            HS_T0();
             __syncthreads();
             h2prologue(a, v, tile, planes, tap_tab, tid);
             h2zero<NT, MT>(h);
             __syncthreads();
-            h2gemm(h, ring, ws, s_in, fc0seg(0), planes, lane, 1);
-            for (int blk = 0; blk < nvb; ++blk) {
-                const bool last = blk == nvb - 1;
-                {
-                    // h += interp(lin_z[blk](latent map)): the block's 512 projected channels, staged in fp32 (see h2epilogue)
-                    GatherTaps<C, 1> g;
-                    gather_setup<C>(g, a.zp + (size_t)v * a.Hl * a.Wl * a.zp_stride + blk * HID, tap_tab, wave, lane);
-#ifndef PNY_H2_LATEISSUE
-                    gather_issue<C, 0>(g, 0, wave);
-#endif
-                    __builtin_amdgcn_sched_barrier(0);
-                    __syncthreads();  // every wave is done reading the planes (previous GEMM)
-#ifdef PNY_H2_LATEISSUE
-                    gather_issue<C, 0>(g, 0, wave);
-#endif
-#ifdef PNY_H2_DOUBLEX
-                    __builtin_amdgcn_s_sleep(4);
-                    __syncthreads();
-#endif
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        h2gather_commit(g, planes, c, wave, lane);
-                        if (c < 3) gather_issue<C, 0>(g, (c + 1) * GCH, wave);
-                    }
-                }
+            gather_setup<C>(g, a.zp + (size_t)v * a.Hl * a.Wl * a.zp_stride, tap_tab, wave, lane);
+            gather_issue<C, 0>(g, 0, wave);   // block 0, chunk 0
+            HS_LAP(HS_PROLOGUE);
+            h2gemm(h, ring, ws, s_in, fc0seg(0), planes, lane);
+            HS_LAP(HS_GEMM);
+            // one per-view block; the last one of a view is a call site of its own so that the compiler sees that the
+            // gather buffers are dead across its fc_1 GEMM (where the other views' running sum takes those registers)
+            auto view_block = [&](int blk, const H2Seg& after, const float* slab_in, int next_c0) {
+                // h += interp(lin_z[blk](latent map)): the block's 512 projected channels in 4 chunks of 128, staged in
+                // fp32 (see h2epilogue).  Chunk 0 is in buffer 0 already (issued before / underneath the previous GEMM);
+                // from here two chunks are in flight: the loads of chunk c + 1 are issued before chunk c is blended.
+                const int cb = blk * HID;
+                HS_LAP(HS_GATHER);
+                __syncthreads();  // every wave is done reading the planes (previous GEMM)
+                HS_LAP(HS_GATHER_WAIT);
+                gather_issue<C, 1>(g, cb + GCH, wave);
+                __builtin_amdgcn_sched_barrier(0);
+                h2gather_commit<0>(g, planes, 0, wave, lane);
+                gather_issue<C, 0>(g, cb + 2 * GCH, wave);
+                __builtin_amdgcn_sched_barrier(0);
+                h2gather_commit<1>(g, planes, 1, wave, lane);
+                gather_issue<C, 1>(g, cb + 3 * GCH, wave);
+                __builtin_amdgcn_sched_barrier(0);
+                h2gather_commit<0>(g, planes, 2, wave, lane);
+                h2gather_commit<1>(g, planes, 3, wave, lane);
+                HS_LAP(HS_GATHER);
                 __syncthreads();  // projection visible
+                HS_LAP(HS_GATHER_WAIT);
                 h2epilogue<true>(h, entry_bias(blk), planes, wave, lane);
-                block_tail(blk, last ? after_view : fc0seg(blk + 1), (last && v > 0) ? slab : nullptr);
+                HS_LAP(HS_EPI);
+                block_tail(blk, after, slab_in, next_c0);
+            };
+#ifdef PNY_H2_NOPREFETCH
+            for (int blk = 0; blk + 1 < nvb; ++blk) {
+                view_block(blk, fc0seg(blk + 1), nullptr, -1);
+                gather_issue<C, 0>(g, (blk + 1) * HID, wave);
             }
+#else
+            for (int blk = 0; blk + 1 < nvb; ++blk) view_block(blk, fc0seg(blk + 1), nullptr, (blk + 1) * HID);
+#endif
+            view_block(nvb - 1, after_view, v > 0 ? slab : nullptr, -1);
             if (a.NS > 1) {
+                HS_T0();
                 if (v + 1 < a.NS) {
                     slab_store<NT, MT>(h, slab);
                 } else {
-                    const float ns = (float)a.NS;
+                    const float rns = 1.0f / (float)a.NS;   // (the fp32 kernel divides; one rounding more here, far inside the bar)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) h[nt][mt][r] = h[nt][mt][r] / ns;
+                            for (int r = 0; r < 16; ++r) h[nt][mt][r] = h[nt][mt][r] * rns;
                 }
+                HS_LAP(HS_SLAB);
             }
         }
         for (int blk = nvb; blk < nb; ++blk) {
+            HS_T0();
             __syncthreads();
+            HS_LAP(HS_EPI_WAIT);
             h2epilogue<false>(h, entry_bias(blk), planes, wave, lane);
-            block_tail(blk, blk + 1 < nb ? fc0seg(blk + 1) : s_in, nullptr);
+            HS_LAP(HS_EPI);
+            block_tail(blk, blk + 1 < nb ? fc0seg(blk + 1) : s_in, nullptr, -1);
         }
         // out = lin_out(relu(h + b_fc1[last])) (reference resnetfc.py:185) + output head (models.py:312-317)
+        HS_T0();
         __syncthreads();
         h2epilogue<false>(h, entry_bias(nb), planes, wave, lane);
         __syncthreads();
@@ -486,7 +576,13 @@ __global__ __launch_bounds__(h2::THREADS, 2) void pny_mlp_h2_kernel(const MlpArg
             const long long s = tile * TM + m;
             if (s < a.n_points) a.out[s * a.d_out + o] = sum;
         }
+        HS_LAP(HS_LINOUT);
     }
+#ifdef PNY_H2_STAMP
+    hs_acc[HS_TOTAL] = h2now() - hs_start;
+    if (lane == 0)
+        for (int i = 0; i < HS_N; ++i) g_h2_stamp_buf[((size_t)blockIdx.x * 8 + wave) * HS_N + i] = hs_acc[i];
+#endif
 }
 
 bool mlp_h2_supports(int n_blocks, int combine_layer) { return n_blocks <= h2::MAX_NB && combine_layer >= 1; }
@@ -501,7 +597,29 @@ void launch_mlp_h2(const MlpArgs& a, int grid, hipStream_t st) {
                                   h2::lds_bytes(h2::MAX_NB));
         attr_set[dev_] = true;
     }
+#ifdef PNY_H2_STAMP
+    static unsigned long long* dbuf = nullptr;
+    const size_t nst = (size_t)grid * 8 * HS_N;
+    if (!dbuf) {
+        (void)hipMalloc((void**)&dbuf, (size_t)1024 * 8 * HS_N * sizeof(unsigned long long));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_h2_stamp_buf), &dbuf, sizeof(dbuf));
+    }
+    (void)hipMemsetAsync(dbuf, 0, nst * sizeof(unsigned long long), st);
+#endif
     hipLaunchKernelGGL(pny_mlp_h2_kernel, dim3(grid), dim3(h2::THREADS), h2::lds_bytes(a.n_blocks), st, a);
+#ifdef PNY_H2_STAMP
+    {
+        std::vector<unsigned long long> hst(nst);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(hst.data(), dbuf, nst * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        double sum[HS_N] = {0};
+        for (size_t i = 0; i < nst; ++i) sum[i % HS_N] += (double)hst[i];
+        static const char* names[HS_N] = {"total", "gemm", "gather-barrier-wait", "gather", "epilogue-barrier-wait", "epilogue", "prologue", "lin_out", "slab"};
+        fprintf(stderr, "[h2 stamp] tiles=%d grid=%d:", a.n_tiles, grid);
+        for (int i = 0; i < HS_N; ++i) fprintf(stderr, " %s=%.1f%%", names[i], 100.0 * sum[i] / sum[0]);
+        fprintf(stderr, " (mean wave cycles %.4g)\n", sum[0] / ((double)grid * 8));
+    }
+#endif
 }
 
 }  // namespace pny
