@@ -11,11 +11,11 @@ for mlp, seed in ((net.mlp_coarse, 1), (net.mlp_fine, 2)):
 net = net.to(dev)
 src, tgt = synth.scene_cameras(3)
 net.encode(torch.zeros(1, 3, 3, 128, 128), torch.from_numpy(src)[None], torch.tensor(131.25), c=torch.tensor([[64.0, 64.0]]), latent=torch.from_numpy(synth.latent(3, 3, 512, 64, 64)))
-net.set_latent_projection("on")
+net.set_latent_projection(os.environ.get("SWEEP_PROJECTION", "on"))
 net.enable_kernel_timing(True)
 rs = np.random.RandomState(0)
 out = []
-for tiles in (64, 128, 192, 256, 300, 384, 520, 700, 1024):
+for tiles in (16, 64, 128, 192, 256, 300, 384, 520, 700, 1024):
     n = tiles * 64
     xyz = torch.from_numpy(rs.uniform(-0.5, 0.5, size=(1, n, 3)).astype(np.float32)).to(dev)
     vd = torch.from_numpy(rs.standard_normal((1, n, 3)).astype(np.float32)).to(dev)
@@ -24,4 +24,5 @@ for tiles in (64, 128, 192, 256, 300, 384, 520, 700, 1024):
         for _ in range(5):
             net(xyz, coarse=True, viewdirs=vd); ms += net.last_mlp_stats(full=True)["kernel_ms"]
     out.append("%d:%.3f" % (tiles, ms / 5))
-print(os.environ.get("PNYOLO_MLP_VARIANT", "auto"), " ".join(out))
+print("variant", os.environ.get("PNYOLO_MLP_VARIANT", "auto"), "precision", os.environ.get("PNYOLO_MLP_PRECISION", "auto"), "projection",
+      os.environ.get("SWEEP_PROJECTION", "on"), "| 64-sample tiles:ms", " ".join(out))
