@@ -112,7 +112,9 @@ def train_main(args):
     """--mode train: the reference's training step (PixelNerfTrainer.calc_losses + optimizer step, trainer.py) replayed on
     the C2 model with its default batch: SB = 4 objects x 3 source views of 128x128 (encoded inside every step with the
     frozen ResNet-34 trunk: --freeze_enc), 128 rays per object (train.py:55), 64 coarse + 32 fine (16 depth) samples,
-    loss = MSE(coarse.rgb) + MSE(fine.rgb), loss.backward(), Adam(lr 1e-4).step().  Single GPU.
+    loss = MSE(coarse.rgb) + MSE(fine.rgb), loss.backward(), Adam(lr 1e-4).step().  With --gpus N every rank trains on its
+    own super-batch (different objects and pixels) and the MLP gradients are averaged with ONE all-reduce per step
+    (pixel_nerf_yolo_amd.dist.allreduce_gradients) before the optimizer step: weak scaling, value = all ranks' rays / max time.
     value = training rays/s.  roofline: GEMM FLOPs executed by the four MLP kernels of a step (forward, stash forward,
     dX chain, weight-gradient GEMMs) / their HIP-event time, against the fp32 MFMA peak."""
     import numpy as np
@@ -125,8 +127,22 @@ def train_main(args):
     from pixel_nerf_yolo_amd.render import NeRFRenderer
     from pixel_nerf_yolo_amd.util import gen_rays
 
+    import torch.distributed as dist
+    from pixel_nerf_yolo_amd import dist as pdist
+
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path for the product)"
-    dev = torch.device("cuda", 0)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = 0 if args.rehearse_one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        if args.rehearse_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     SB, NSV, H, W, RB, KC, KF, KFD = 4, NS, 128, 128, 128, 64, 32, 16
     steps = args.steps if args.steps is not None else 10
     net = make_model(pconf.default_mv()["model"], stop_encoder_grad=True)
@@ -142,8 +158,9 @@ def train_main(args):
     ren = NeRFRenderer(n_coarse=KC, n_fine=KF, n_fine_depth=KFD, depth_std=0.01, white_bkgd=True).train()
     par = ren.bind_parallel(net, None).train()
     opt = torch.optim.Adam([p_ for p_ in net.parameters() if p_.requires_grad], lr=1e-4)
-    rs = np.random.RandomState(5)
-    images = torch.from_numpy(np.stack([synth.images(80 + i, NSV, H, W) for i in range(SB)])).to(dev)     # (SB, NS, 3, H, W)
+    params = [p_ for p_ in net.parameters() if p_.requires_grad]
+    rs = np.random.RandomState(5 + rank)
+    images = torch.from_numpy(np.stack([synth.images(80 + SB * rank + i, NSV, H, W) for i in range(SB)])).to(dev)     # (SB, NS, 3, H, W)
     poses = torch.from_numpy(np.stack([synth.scene_cameras(NSV, radius=1.3 + 0.02 * i)[0] for i in range(SB)]))
     focal = torch.full((SB,), FOCAL128)
     tgt = torch.from_numpy(np.stack([synth.pose_spherical(120.0 + 10 * i, -20.0, 1.3) for i in range(SB)]))
@@ -151,7 +168,7 @@ def train_main(args):
     gt_all = torch.from_numpy(rs.uniform(0, 1, size=(SB, H * W, 3)).astype(np.float32)).to(dev)
 
     def step(i):
-        pix = torch.from_numpy(np.random.RandomState(1000 + i).randint(0, H * W, size=(SB, RB))).to(dev)
+        pix = torch.from_numpy(np.random.RandomState(1000 + i + 7919 * rank).randint(0, H * W, size=(SB, RB))).to(dev)
         rays = torch.gather(all_rays, 1, pix[..., None].expand(-1, -1, 8))
         gt = torch.gather(gt_all, 1, pix[..., None].expand(-1, -1, 3))
         net.encode(images, poses, focal)
@@ -159,12 +176,19 @@ def train_main(args):
         loss = torch.nn.functional.mse_loss(out["coarse"]["rgb"], gt) + torch.nn.functional.mse_loss(out["fine"]["rgb"], gt)
         opt.zero_grad()
         loss.backward()
+        if world > 1:
+            pdist.allreduce_gradients(params)   # one 27 MB collective (staged through the host under the gloo rehearsal)
         opt.step()
         return loss
 
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     for i in range(max(args.warmup, 2)):
         l0 = step(i)
-    torch.cuda.synchronize()
+    fence()
     net.enable_kernel_timing(True)
     k_ms, k_fl = [0.0] * 4, [0.0] * 4
     t0 = time.perf_counter()
@@ -179,8 +203,12 @@ def train_main(args):
             k_fl[1 + j] += b["flops"][j]
         ff, fm = net.last_flush_stats()       # deferred mode: ONE weight-gradient GEMM per MLP over all scenes' tiles
         k_ms[3] += fm
-    torch.cuda.synchronize()
+    fence()
     elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device="cpu" if args.rehearse_one_gpu else dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
     net.enable_kernel_timing(False)
     assert bool(torch.isfinite(loss))
     names = ["forward (projected latent)", "stash forward (reference order)", "dX chain", "weight-gradient GEMMs + reduce"]
@@ -188,12 +216,13 @@ def train_main(args):
     # against the step's WALL time (a lower bound on the kernels' own efficiency)
     tot_ms, tot_fl = elapsed * 1e3, sum(k_fl)
     out = {
-        "metric": "training rays/sec, 64+32 samples/ray, 3-view 128x128 conditioning", "value": SB * RB * steps / elapsed,
-        "unit": "rays/s", "n_gpus": 1, "steps": steps, "warmup": max(args.warmup, 2), "ms_per_step": elapsed / steps * 1e3,
+        "metric": "training rays/sec, 64+32 samples/ray, 3-view 128x128 conditioning", "value": world * SB * RB * steps / elapsed,
+        "unit": "rays/s", "n_gpus": world, "n_ranks_seen": dist.get_world_size() if dist.is_initialized() else 1, "steps": steps, "warmup": max(args.warmup, 2), "ms_per_step": elapsed / steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "train step of the C2 model: SB=4 objects x 3 views 128x128 (frozen ResNet34 trunk encoded "
                                "every step), 128 rays/object, 64 coarse + 32 fine (16 depth), MSE coarse+fine, Adam",
-                   "rays_per_step": SB * RB},
+                   "rays_per_step": world * SB * RB, "rays_per_step_this_rank": SB * RB,
+                   "parallelism": "dp%d: one super-batch per rank, 1 gradient all-reduce (27 MB fp32) per step" % world},
         "loss_first": float(l0), "loss_last": float(loss),
         "roofline": {"bound": "mfma", "kernel": "MLP kernels of a training step", "achieved": tot_fl / (tot_ms * 1e-3) / 1e12,
                      "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
@@ -204,7 +233,12 @@ def train_main(args):
                                  for n_, m_, f_ in zip(names, k_ms, k_fl)]},
         "cpu_baseline": None,
     }
-    print(json.dumps(out), flush=True)
+    if args.rehearse_one_gpu:
+        out["rehearsal"] = "ranks share ONE GPU, gloo transport: mechanics check, not a measurement"
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
     return 0
 
 

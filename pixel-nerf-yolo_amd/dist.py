@@ -85,3 +85,46 @@ def render_frame_sharded(render_fn, pose, width, height, focal, z_near, z_far, c
         tile = torch.zeros(0, 4, device=dev, dtype=torch.float32)
     full = gather_tiles(tile, n, per, group)
     return full[:, :3].reshape(height, width, 3), full[:, 3].reshape(height, width)
+
+
+def allreduce_gradients(params, group=None, bucket_bytes=64 << 20, average=True):
+    """Data-parallel training over ranks that each ran ``loss.backward()`` on their own super-batch (the reference trains on
+    one GPU; its DataParallel splits rays, not objects -- SURVEY.md 2.3): sum the ``.grad`` of ``params`` over the ranks and
+    divide by the world size, in flat buckets of at most ``bucket_bytes`` (the two MLPs hold 27 MB of fp32 gradients: ONE
+    collective, ring all-reduce on xGMI is per-link bound, so fewer and larger is better).  Parameters without a gradient on
+    this rank contribute zeros, so every rank issues the same collectives.  No-op for a single process.  Returns the number of
+    collectives issued."""
+    world, _ = _world(group)
+    params = [p for p in params if p.requires_grad]
+    if world == 1 or not params:
+        return 0
+    buckets, cur, cur_bytes = [], [], 0
+    for p in params:
+        nbytes = p.numel() * 4
+        if cur and cur_bytes + nbytes > bucket_bytes:
+            buckets.append(cur)
+            cur, cur_bytes = [], 0
+        cur.append(p)
+        cur_bytes += nbytes
+    if cur:
+        buckets.append(cur)
+    for bucket in buckets:
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(torch.float32) for p in bucket])
+        if flat.is_cuda and dist.get_backend(group) == "gloo":   # rehearsals on one GPU: gloo moves host memory
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            flat.copy_(host)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if average:
+            flat /= world
+        off = 0
+        for p in bucket:
+            n = p.numel()
+            g = flat[off:off + n].view_as(p).to(p.dtype)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            off += n
+    return len(buckets)

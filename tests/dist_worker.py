@@ -29,6 +29,40 @@ def run(rank, world, port, n, q):
     dist.destroy_process_group()
 
 
+def run_grads(rank, world, port, q):
+    """allreduce_gradients over gloo: every rank holds different gradients (one parameter has none on rank 1, one is frozen);
+    afterwards every rank must hold the mean, in one collective for the small bucket limit's worth of tensors."""
+    import torch
+    import torch.distributed as dist
+    import pnyolo_pkg
+    pnyolo_pkg.load()
+    from pixel_nerf_yolo_amd import dist as pdist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shapes = [(512, 42), (512,), (512, 512), (4, 512), (4,)]
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+    frozen = torch.nn.Parameter(torch.zeros(3), requires_grad=False)
+    for i, p in enumerate(params):
+        g = torch.Generator().manual_seed(100 * rank + i)
+        p.grad = torch.randn(p.shape, generator=g)
+    if rank == 1:
+        params[1].grad = None                       # e.g. a parameter the rank's batch did not touch
+    n_one = pdist.allreduce_gradients(params + [frozen])                      # everything fits one bucket
+    expect = []
+    for i, s in enumerate(shapes):
+        gs = [torch.randn(s, generator=torch.Generator().manual_seed(100 * r + i)) for r in range(world)]
+        if i == 1:
+            gs[1] = torch.zeros(s)
+        expect.append(sum(gs) / world)
+    ok = all(torch.allclose(p.grad, e, rtol=0, atol=1e-7) for p, e in zip(params, expect)) and frozen.grad is None
+    n_many = pdist.allreduce_gradients(params, bucket_bytes=512 * 512 * 4)   # second pass: several buckets, values = mean of means
+    ok = ok and all(torch.allclose(p.grad, e, rtol=0, atol=1e-7) for p, e in zip(params, expect))
+    q.put((rank, bool(ok), n_one, n_many))
+    dist.destroy_process_group()
+
+
 def run_render(rank, world, port, q):
     """world_size ranks sharing cuda:0 (gloo: RCCL refuses duplicate devices) render ONE frame with
     dist.render_frame_sharded through the HIP path: each rank generates and renders its own ray range with explicit

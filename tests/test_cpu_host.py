@@ -209,6 +209,22 @@ def test_render_sharded_gloo_world2(n):
     assert res == [(0, True, (n, 3)), (1, True, (n, 3))]
 
 
+def test_allreduce_gradients_gloo_world2():
+    """Data-parallel training's one exchange step (dist.allreduce_gradients): mean over ranks, missing gradients count as
+    zeros, frozen parameters are skipped, bucket limit respected."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    import dist_worker
+    procs = [ctx.Process(target=dist_worker.run_grads, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True, 1, 3), (1, True, 1, 3)]
+
+
 def test_bench_json_contract_fields():
     import json
     import subprocess
