@@ -5,11 +5,13 @@ Data and image adapters either side of the rendering path:
 Host-side Python mirroring the reference's interface (same class names, constructor arguments, item dictionaries):
   SRNDataset   reference src/data/SRNDataset.py:10-136
   YOLODataset  reference src/data/YOLODataset.py:10-225 (incl. the anchor / cell target assignment)
-  get_split_dataset  reference src/data/__init__.py:12-76 (types ``srn`` and ``yolo``)
+  DVRDataset   reference src/data/DVRDataset.py:11-275 (ShapeNet / NMR renderings and the DTU sub-format)
+  ColorJitterDataset  reference src/data/data_util.py:13-55 (training-time augmentation of ``dvr_dtu`` and ``yolo``)
+  get_split_dataset  reference src/data/__init__.py:12-76 (types ``srn``, ``dvr``, ``dvr_gen``, ``dvr_dtu`` and ``yolo``)
   psnr / ssim / write_views  what eval/eval.py:291-359 does with skimage / imageio
 
-PARITY UNPINNED against the third-party libraries the reference uses here -- imageio (decoding), cv2 (resize),
-skimage (metrics) are not importable in this environment, so the reference's classes cannot be imported to capture
+PARITY UNPINNED against the third-party libraries the reference uses here -- imageio (decoding), cv2 (resize, projection-
+matrix decomposition), torchvision (colour jitter), skimage (metrics) are not importable in this environment, so the reference's classes cannot be imported to capture
 goldens.  Decoding / encoding goes through Pillow; ``cv2.resize`` (bilinear) is restated with
 ``F.interpolate(mode="bilinear", align_corners=False)``, which agrees with OpenCV's INTER_LINEAR up to its fixed-point
 rounding on uint8; the metrics follow the published definitions (skimage ``structural_similarity`` defaults: 7x7 uniform
@@ -224,23 +226,243 @@ class YOLODataset(torch.utils.data.Dataset):
 
 
 def get_split_dataset(dataset_type, datadir, want_split="all", training=True, **kwargs):
-    """reference src/data/__init__.py:12-76 for the dataset types implemented here (no colour-jitter wrapper)."""
-    flags = {}
+    """reference src/data/__init__.py:12-76: dataset class + flags per type name; the training split of ``dvr_dtu`` and
+    ``yolo`` is wrapped in the colour-jitter augmentation.  (``multi_obj`` is not implemented.)"""
+    flags, aug, aug_flags = {}, None, {}
     if dataset_type == "srn":
         dset_class = SRNDataset
+    elif dataset_type.startswith("dvr"):
+        dset_class = DVRDataset
+        if dataset_type == "dvr_gen":
+            flags["list_prefix"] = "gen_"
+        elif dataset_type == "dvr_dtu":
+            flags.update(list_prefix="new_", sub_format="dtu", scale_focal=False, z_near=0.1, z_far=5.0)
+            if training:
+                flags["max_imgs"] = 49
+            aug, aug_flags = ColorJitterDataset, {"extra_inherit_attrs": ["sub_format"]}
     elif dataset_type == "yolo":
         dset_class = YOLODataset
         flags["z_near"], flags["z_far"] = 1, 13.0
+        aug = ColorJitterDataset
     else:
-        raise NotImplementedError("dataset type %r is not implemented here (srn, yolo)" % dataset_type)
+        raise NotImplementedError("dataset type %r is not implemented here (srn, dvr, dvr_gen, dvr_dtu, yolo)" % dataset_type)
     want_train = want_split not in ("val", "test")
     want_val = want_split not in ("train", "test")
     want_test = want_split not in ("train", "val")
     sets = [dset_class(datadir, stage=st, **flags, **kwargs) if want else None
             for st, want in (("train", want_train), ("val", want_val), ("test", want_test))]
+    if sets[0] is not None and aug is not None:
+        sets[0] = aug(sets[0], **aug_flags)
     if want_split in ("train", "val", "test"):
         return sets[("train", "val", "test").index(want_split)]
     return tuple(sets)
+
+
+# ------------------------------------------------------------------ DVR (ShapeNet 64x64 / NMR, DTU)
+def decompose_projection(P):
+    """cv2.decomposeProjectionMatrix(P)[:3] for a 3x4 projection P = K [R | -R C]: the upper-triangular calibration K with a
+    positive diagonal and the rotation R from an RQ factorisation of P[:, :3], and the camera centre C as a homogeneous
+    4-vector (the null vector of P, scaled like OpenCV's: unit norm)."""
+    import scipy.linalg
+    P = np.asarray(P, dtype=np.float64)
+    K, R = scipy.linalg.rq(P[:, :3])
+    sign = np.diag(np.sign(np.diag(K)))          # RQ is unique up to the signs of K's diagonal
+    K, R = K @ sign, sign @ R
+    _, _, vt = np.linalg.svd(P)
+    c = vt[-1]
+    return K, R, c[:, None]
+
+
+class DVRDataset(torch.utils.data.Dataset):
+    """Objects of the DVR release (Niemeyer et al. 2020): <root>/<category>/<object>/{image/*.png|jpg, mask/*.png,
+    cameras.npz}, split lists <root>/<category>/<list_prefix><stage>.lst.  Item = {path, img_id, focal, images (NV, 3, H, W)
+    in [-1, 1], poses (NV, 4, 4) camera-to-world in the renderer's convention, masks?, and c (DTU) or bbox (ShapeNet)}."""
+
+    def __init__(self, path, stage="train", list_prefix="softras_", image_size=None, sub_format="shapenet", scale_focal=True,
+                 max_imgs=100000, z_near=1.2, z_far=4.0, skip_step=None, conf=None):
+        super().__init__()
+        assert os.path.exists(path), path
+        assert stage in ("train", "val", "test")
+        self.base_path, self.stage = path, stage
+        self.all_objs = []
+        for cat_dir in (d for d in glob.glob(os.path.join(path, "*")) if os.path.isdir(d)):
+            lst = os.path.join(cat_dir, list_prefix + stage + ".lst")
+            if os.path.exists(lst):
+                with open(lst) as fh:
+                    self.all_objs += [(os.path.basename(cat_dir), os.path.join(cat_dir, ln.strip())) for ln in fh.readlines()]
+        self.image_to_tensor, self.mask_to_tensor = image_to_tensor_balanced, mask_to_tensor
+        self.image_size = image_size
+        flip_yz = torch.diag(torch.tensor([1.0, -1.0, -1.0, 1.0]))
+        # world frame: DTU keeps its axes up to the y/z flip, ShapeNet's z-up objects are turned to y-up
+        self._coord_trans_world = flip_yz if sub_format == "dtu" else torch.tensor(
+            [[1.0, 0, 0, 0], [0, 0, -1.0, 0], [0, 1.0, 0, 0], [0, 0, 0, 1.0]])
+        self._coord_trans_cam = flip_yz            # OpenCV camera (y down, z forward) -> OpenGL camera
+        self.sub_format, self.scale_focal, self.max_imgs = sub_format, scale_focal, max_imgs
+        self.z_near, self.z_far, self.lindisp = z_near, z_far, False
+
+    def __len__(self):
+        return len(self.all_objs)
+
+    def __getitem__(self, index):
+        _, root = self.all_objs[index]
+        rgb_paths = sorted(f for f in glob.glob(os.path.join(root, "image", "*")) if f.endswith((".jpg", ".png")))
+        mask_paths = sorted(glob.glob(os.path.join(root, "mask", "*.png"))) or [None] * len(rgb_paths)
+        sel = np.arange(len(rgb_paths))
+        if len(rgb_paths) > self.max_imgs:
+            sel = np.random.choice(len(rgb_paths), self.max_imgs, replace=False)
+            rgb_paths, mask_paths = [rgb_paths[i] for i in sel], [mask_paths[i] for i in sel]
+        cams = np.load(os.path.join(root, "cameras.npz"))
+        dtu = self.sub_format != "shapenet"
+        imgs, poses, masks, bboxes = [], [], [], []
+        focal, intr_sum = None, torch.zeros(4, dtype=torch.float64)     # DTU: fx, fy, cx, cy averaged over the views
+        for i, rgb_path, mask_path in zip(sel, rgb_paths, mask_paths):
+            img = imread(rgb_path)[..., :3]
+            # scale_focal: intrinsics are given for an image spanning [-1, 1]
+            xs, ys, delta = (img.shape[1] / 2.0, img.shape[0] / 2.0, 1.0) if self.scale_focal else (1.0, 1.0, 0.0)
+            if dtu:
+                K, R, t = decompose_projection(cams["world_mat_%d" % i][:3])
+                K = K / K[2, 2]
+                pose = np.eye(4, dtype=np.float32)
+                pose[:3, :3] = R.T
+                pose[:3, 3] = (t[:3] / t[3])[:, 0]
+                scale = cams.get("scale_mat_%d" % i)
+                if scale is not None:                                # normalisation of the scene into the unit sphere
+                    pose[:3, 3:] -= scale[:3, 3:]
+                    pose[:3, 3:] /= np.diagonal(scale[:3, :3])[..., None]
+                intr_sum += torch.tensor([K[0, 0] * xs, K[1, 1] * ys, (K[0, 2] + delta) * xs, (K[1, 2] + delta) * ys])
+            else:
+                if "world_mat_inv_%d" % i in cams:
+                    pose = cams["world_mat_inv_%d" % i]
+                else:
+                    w = cams["world_mat_%d" % i]
+                    if w.shape[0] == 3:
+                        w = np.vstack((w, np.array([0, 0, 0, 1])))
+                    pose = np.linalg.inv(w)
+                intr = cams["camera_mat_%d" % i]
+                assert abs(intr[0, 0] - intr[1, 1]) < 1e-9
+                f = intr[0, 0] * xs
+                assert focal is None or abs(f - focal) < 1e-5, "views of one object must share the focal length"
+                focal = f
+            poses.append(self._coord_trans_world @ torch.tensor(pose, dtype=torch.float32) @ self._coord_trans_cam)
+            imgs.append(self.image_to_tensor(img))
+            if mask_path is not None:
+                mask = imread(mask_path)
+                mask = (mask[..., None] if mask.ndim == 2 else mask)[..., :1]
+                rows, cols = np.where(np.any(mask, axis=1))[0], np.where(np.any(mask, axis=0))[0]
+                if len(rows) == 0:
+                    raise RuntimeError("empty mask for " + rgb_path)
+                masks.append(self.mask_to_tensor(mask))
+                bboxes.append(torch.tensor([cols[0], rows[0], cols[-1], rows[-1]], dtype=torch.float32))
+        images, poses = torch.stack(imgs), torch.stack(poses)
+        masks = torch.stack(masks) if masks else None
+        if dtu:
+            intr = (intr_sum / len(rgb_paths)).to(torch.float32)
+            focal, c, bbox = intr[:2].clone(), intr[2:].clone(), None
+        else:
+            focal, c, bbox = focal, None, (torch.stack(bboxes) if bboxes else [])
+        if self.image_size is not None and tuple(images.shape[-2:]) != tuple(self.image_size):
+            scale = self.image_size[0] / images.shape[-2]
+            focal = focal * scale
+            if dtu:
+                c = c * scale
+            elif len(bbox):
+                bbox = bbox * scale
+            images = F.interpolate(images, size=tuple(self.image_size), mode="area")
+            if masks is not None:
+                masks = F.interpolate(masks, size=tuple(self.image_size), mode="area")
+        item = {"path": root, "img_id": index, "focal": focal, "images": images, "poses": poses}
+        if masks is not None:
+            item["masks"] = masks
+        if dtu:
+            item["c"] = c
+        else:
+            item["bbox"] = bbox
+        return item
+
+
+# ------------------------------------------------------------------ colour jitter (training-time augmentation)
+def _gray(img):
+    return (0.2989 * img[..., 0, :, :] + 0.587 * img[..., 1, :, :] + 0.114 * img[..., 2, :, :]).unsqueeze(-3)
+
+
+def _blend(a, b, ratio):
+    return (ratio * a + (1.0 - ratio) * b).clamp(0.0, 1.0)
+
+
+def adjust_brightness(img, factor):
+    """torchvision ``adjust_brightness`` on a float (3, H, W) image in [0, 1]: blend with black."""
+    return _blend(img, torch.zeros_like(img), factor)
+
+
+def adjust_contrast(img, factor):
+    """blend with the mean grey level of the image."""
+    return _blend(img, _gray(img).mean(dim=(-3, -2, -1), keepdim=True), factor)
+
+
+def adjust_saturation(img, factor):
+    """blend with the grey image."""
+    return _blend(img, _gray(img), factor)
+
+
+def adjust_hue(img, factor):
+    """rotate the hue by ``factor`` (in turns, |factor| <= 0.5): RGB -> HSV, h <- (h + factor) mod 1, HSV -> RGB."""
+    assert -0.5 <= factor <= 0.5
+    r, g, b = img.unbind(-3)
+    maxc, minc = img.max(-3).values, img.min(-3).values
+    eqc = maxc == minc
+    cr = maxc - minc
+    ones = torch.ones_like(maxc)
+    s = cr / torch.where(eqc, ones, maxc)
+    crd = torch.where(eqc, ones, cr)
+    rc, gc, bc = (maxc - r) / crd, (maxc - g) / crd, (maxc - b) / crd
+    hr = (maxc == r) * (bc - gc)
+    hg = ((maxc == g) & (maxc != r)) * (2.0 + rc - bc)
+    hb = ((maxc != g) & (maxc != r)) * (4.0 + gc - rc)
+    h = torch.fmod((hr + hg + hb) / 6.0 + 1.0, 1.0)
+    h = (h + factor) % 1.0
+    i = torch.floor(h * 6.0)
+    f = h * 6.0 - i
+    i = i.to(torch.int32) % 6
+    v = maxc
+    p, q, t = (v * (1.0 - s)).clamp(0, 1), (v * (1.0 - s * f)).clamp(0, 1), (v * (1.0 - s * (1.0 - f))).clamp(0, 1)
+    sel = i.unsqueeze(-3) == torch.arange(6, device=img.device).view(-1, 1, 1)
+    a1 = torch.stack((v, q, p, p, t, v), dim=-3)
+    a2 = torch.stack((t, v, v, q, p, p), dim=-3)
+    a3 = torch.stack((p, p, t, v, v, q), dim=-3)
+    a4 = torch.stack((a1, a2, a3), dim=-4)
+    return torch.einsum("...ijk,...xijk->...xjk", sel.to(img.dtype), a4)
+
+
+class ColorJitterDataset(torch.utils.data.Dataset):
+    """Wraps a dataset: ONE random (hue, saturation, brightness, contrast) draw per item, applied to all of its views
+    (images are mapped from [-1, 1] to [0, 1] and back; order saturation, hue, contrast, brightness)."""
+
+    def __init__(self, base_dset, hue_range=0.1, saturation_range=0.1, brightness_range=0.1, contrast_range=0.1,
+                 extra_inherit_attrs=()):
+        self.hue_range = [-hue_range, hue_range]
+        self.saturation_range = [1 - saturation_range, 1 + saturation_range]
+        self.brightness_range = [1 - brightness_range, 1 + brightness_range]
+        self.contrast_range = [1 - contrast_range, 1 + contrast_range]
+        self.base_dset = base_dset
+        for attr in ["z_near", "z_far", "base_path", "image_to_tensor", *extra_inherit_attrs]:
+            setattr(self, attr, getattr(base_dset, attr))
+
+    def apply_color_jitter(self, images):
+        hue, sat = np.random.uniform(*self.hue_range), np.random.uniform(*self.saturation_range)
+        bri, con = np.random.uniform(*self.brightness_range), np.random.uniform(*self.contrast_range)
+        for i in range(len(images)):
+            t = (images[i] + 1.0) * 0.5
+            t = adjust_brightness(adjust_contrast(adjust_hue(adjust_saturation(t, sat), hue), con), bri)
+            images[i] = t * 2.0 - 1.0
+        return images
+
+    def __len__(self):
+        return len(self.base_dset)
+
+    def __getitem__(self, idx):
+        data = self.base_dset[idx]
+        data["images"] = self.apply_color_jitter(data["images"])
+        return data
 
 
 # ------------------------------------------------------------------ metrics / writers (eval/eval.py:291-359)

@@ -128,3 +128,113 @@ def test_metrics_and_writer(tmp_path):
     assert back.shape == (24, 20, 3) and np.array_equal(back, (img[1] * 255).astype(np.uint8))
     assert pdata.imread(str(tmp_path / "out" / "000003_compare.png")).shape == (24, 40, 3)
     assert abs(p - np.mean([pdata.psnr(img[i], gt[i]) for i in range(2)])) < 1e-9 and 0 < s < 1
+
+
+def _rot(rs):
+    q, _ = np.linalg.qr(rs.randn(3, 3))
+    return q * np.sign(np.linalg.det(q))
+
+
+def _dvr_tree(root, sub_format, n_views=3, size=(12, 16)):
+    """<root>/<cat>/<obj>/{image, mask, cameras.npz} + split list, with known cameras."""
+    rs = np.random.RandomState(3)
+    cat = os.path.join(root, "02958343")
+    obj = os.path.join(cat, "obj0")
+    os.makedirs(os.path.join(obj, "image"))
+    os.makedirs(os.path.join(obj, "mask"))
+    prefix = "new_" if sub_format == "dtu" else "softras_"
+    with open(os.path.join(cat, prefix + "val.lst"), "w") as fh:
+        fh.write("obj0\n")
+    H, W = size
+    cams, truth = {}, []
+    for v in range(n_views):
+        img = rs.randint(0, 255, size=(H, W, 3)).astype(np.uint8)
+        pdata.imwrite(os.path.join(obj, "image", "%04d.png" % v), img)
+        mask = np.zeros((H, W), np.uint8)
+        mask[2 + v:8, 3:10 + v] = 255
+        pdata.imwrite(os.path.join(obj, "mask", "%04d.png" % v), mask)
+        R, C = _rot(rs), rs.uniform(-1, 1, 3)
+        if sub_format == "dtu":
+            K = np.array([[30.0 + v, 0.0, W / 2 + 0.5], [0.0, 31.0 + v, H / 2 - 0.5], [0.0, 0.0, 1.0]])
+            P = np.eye(4)
+            P[:3] = K @ np.hstack([R, (-R @ C)[:, None]])
+            cams["world_mat_%d" % v] = P * (1.0 + 0.1 * v)              # a projection matrix is defined up to scale
+            S = np.diag([2.0, 2.0, 2.0, 1.0])
+            S[:3, 3] = [0.1, -0.2, 0.3]
+            cams["scale_mat_%d" % v] = S
+            c2w = np.eye(4)
+            c2w[:3, :3], c2w[:3, 3] = R.T, (C - S[:3, 3]) / 2.0
+            truth.append((img, c2w, K))
+        else:
+            w2c = np.eye(4)
+            w2c[:3, :3], w2c[:3, 3] = R, -R @ C
+            cams["world_mat_%d" % v] = w2c[:3] if v == 0 else w2c       # both stored shapes occur in the release
+            cams["camera_mat_%d" % v] = np.diag([2.5, 2.5, 1.0, 1.0])
+            truth.append((img, np.linalg.inv(w2c), None))
+    np.savez(os.path.join(obj, "cameras.npz"), **cams)
+    return root, obj, truth
+
+
+def test_dvr_shapenet_contract(tmp_path):
+    root, obj, truth = _dvr_tree(str(tmp_path), "shapenet")
+    ds = pdata.get_split_dataset("dvr", root, want_split="val", training=False)
+    assert isinstance(ds, pdata.DVRDataset) and len(ds) == 1 and (ds.z_near, ds.z_far, ds.lindisp) == (1.2, 4.0, False)
+    it = ds[0]
+    assert it["path"] == obj and it["images"].shape == (3, 3, 12, 16) and it["masks"].shape == (3, 1, 12, 16) and "c" not in it
+    assert torch.equal(it["images"][1], torch.from_numpy(truth[1][0]).permute(2, 0, 1).float() / 255 * 2 - 1)
+    assert abs(float(it["focal"]) - 2.5 * 16 / 2) < 1e-6            # scale_focal: camera_mat is for an image spanning [-1, 1]
+    world = np.array([[1.0, 0, 0, 0], [0, 0, -1.0, 0], [0, 1.0, 0, 0], [0, 0, 0, 1.0]])     # z-up object -> y-up world
+    cam = np.diag([1.0, -1.0, -1.0, 1.0])
+    for v in range(3):
+        assert np.allclose(it["poses"][v].numpy(), world @ truth[v][1] @ cam, atol=1e-5)
+    assert it["bbox"][1].tolist() == [3.0, 3.0, 10.0, 7.0]          # [cmin, rmin, cmax, rmax] of the mask
+    it2 = pdata.DVRDataset(root, stage="val", image_size=(6, 8))[0]
+    assert it2["images"].shape == (3, 3, 6, 8) and abs(float(it2["focal"]) - 10.0) < 1e-6
+    assert torch.allclose(it2["bbox"], it["bbox"] * 0.5) and torch.allclose(it2["images"], torch.nn.functional.avg_pool2d(it["images"], 2), atol=1e-6)
+    assert len(pdata.DVRDataset(root, stage="train")) == 0          # no list for that stage
+
+
+def test_dvr_dtu_contract_and_colour_jitter(tmp_path):
+    root, obj, truth = _dvr_tree(str(tmp_path), "dtu")
+    ds = pdata.get_split_dataset("dvr_dtu", root, want_split="val", training=False)
+    assert (ds.sub_format, ds.z_near, ds.z_far, ds.max_imgs) == ("dtu", 0.1, 5.0, 100000)
+    it = ds[0]
+    assert "bbox" not in it and it["images"].shape == (3, 3, 12, 16)
+    # intrinsics: recovered from the projection matrices (up to scale), averaged over the views, in pixels (scale_focal False)
+    Ks = np.stack([t[2] for t in truth])
+    assert np.allclose(it["focal"].numpy(), [Ks[:, 0, 0].mean(), Ks[:, 1, 1].mean()], atol=1e-3)
+    assert np.allclose(it["c"].numpy(), [Ks[:, 0, 2].mean(), Ks[:, 1, 2].mean()], atol=1e-3)
+    flip = np.diag([1.0, -1.0, -1.0, 1.0])
+    for v in range(3):                                               # camera centre normalised by scale_mat, y / z flipped
+        assert np.allclose(it["poses"][v].numpy(), flip @ truth[v][1] @ flip, atol=1e-4)
+    # training split: at most 49 views, wrapped in the colour jitter (one draw per item, all views alike)
+    os.rename(os.path.join(root, "02958343", "new_val.lst"), os.path.join(root, "02958343", "new_train.lst"))
+    tr = pdata.get_split_dataset("dvr_dtu", root, want_split="train", training=True)
+    assert isinstance(tr, pdata.ColorJitterDataset) and tr.base_dset.max_imgs == 49 and tr.sub_format == "dtu" and tr.z_far == 5.0
+    np.random.seed(0)
+    jit = tr[0]["images"]
+    assert jit.shape == (3, 3, 12, 16) and float(jit.min()) >= -1.0 and float(jit.max()) <= 1.0
+    assert 1e-3 < float((jit - it["images"]).abs().max()) < 0.6     # changed, by at most a 10 % jitter of each kind
+    still = pdata.ColorJitterDataset(ds, 0.0, 0.0, 0.0, 0.0)[0]["images"]
+    assert torch.allclose(still, it["images"], atol=2e-6)            # zero ranges: identity (hue 0, factors 1)
+
+
+def test_colour_adjustments_follow_their_definitions():
+    g = torch.Generator().manual_seed(1)
+    img = torch.rand(3, 5, 7, generator=g)
+    gray = 0.2989 * img[0] + 0.587 * img[1] + 0.114 * img[2]
+    assert torch.allclose(pdata.adjust_saturation(img, 0.0), gray.expand(3, -1, -1), atol=1e-6)
+    assert torch.allclose(pdata.adjust_contrast(img, 0.0), gray.mean().expand(3, 5, 7), atol=1e-6)
+    assert torch.allclose(pdata.adjust_brightness(img, 0.5), img * 0.5)
+    assert float(pdata.adjust_brightness(img, 3.0).max()) <= 1.0
+    # hue: a third of a turn permutes pure primaries; a full turn there and back is the identity
+    prim = torch.tensor([1.0, 0.0, 0.0]).view(3, 1, 1)
+    assert torch.allclose(pdata.adjust_hue(prim, 1.0 / 3.0), torch.tensor([0.0, 1.0, 0.0]).view(3, 1, 1), atol=1e-6)
+    assert torch.allclose(pdata.adjust_hue(pdata.adjust_hue(img, 0.3), -0.3), img, atol=2e-6)
+    import colorsys
+    for _ in range(20):
+        r, gg, b = (float(x) for x in torch.rand(3, generator=g))
+        h, s, v = colorsys.rgb_to_hsv(r, gg, b)
+        want = colorsys.hsv_to_rgb((h + 0.07) % 1.0, s, v)
+        got = pdata.adjust_hue(torch.tensor([r, gg, b]).view(3, 1, 1), 0.07).flatten().tolist()
+        assert np.allclose(got, want, atol=1e-6)
