@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PNY_ABI_VERSION 7
+#define PNY_ABI_VERSION 8
 
 typedef enum pny_status {
     PNY_OK = 0,
@@ -275,6 +275,14 @@ int pny_scene_enable_timing(pny_scene* s, int enable);
  * parameter's shape (fp32, contiguous) that the backward calls write / add into.  NULL unbinds.  Borrowed until
  * rebound; parameters without a bound target get no gradient. */
 int pny_model_bind_grad(pny_model* m, const char* name, float* grad_dev);
+
+/* Gradient w.r.t. the scene's latent -- the backward of `F.grid_sample` (src/model/encoder.py:101) composed with lin_z
+ * (src/model/resnetfc.py:176-182), i.e. what reaches `encoder.latent` in the reference when the encoder trains:
+ * grad_dev is a caller-owned, caller-zeroed fp32 buffer of the latent's shape in the library's layout (ns, Hl, Wl, L)
+ * (channel-last); every backward call on the scene ADDS into it (float atomics: reproducible to fp32 rounding, not bit for
+ * bit).  NULL unbinds.  d_latent must be a multiple of 256.  The encoder itself is not differentiated here: the gradient is
+ * handed to whatever produced the latent (pny_scene_set_latent). */
+int pny_scene_bind_latent_grad(pny_scene* s, float* grad_dev);
 
 /* Backward of pny_query: d_out_dev (n, d_out) = dL/d(out).  accumulate = 0 overwrites the bound gradients of the
  * selected MLP, 1 adds to them. */

@@ -202,6 +202,28 @@ static int pack_mlp(pny_model* m, const std::string& pre, MlpWeights& w, MlpWeig
         if ((rc = packed_h2(p + ".fc_0.weight", HID, HID, &wt.h2_fc0[b]))) return rc;
         if ((rc = packed_h2(p + ".fc_1.weight", HID, HID, &wt.h2_fc1[b]))) return rc;
     }
+    // stacked transposed lin_z for the latent gradient (latent_grad.hip): W_cat[c][b * 512 + f] = lin_z[b].weight[f][c],
+    // n-tile-major [c / 32][k-iteration][lane] float4 like the projection weights (encoder.hip build_pixel_linear)
+    wt.wzT_cat = nullptr;
+    if (nvb > 0) {
+        const int Lc = d.d_latent, Kc = nvb * HID, Jc = Kc / 8;
+        while (plan.blob.size() % 16) plan.blob.push_back(0.f);
+        const size_t off = plan.blob.size();
+        plan.blob.resize(off + (size_t)Lc * Kc);
+        for (int b = 0; b < nvb; ++b) {
+            const std::string name = pre + "lin_z." + std::to_string(b) + ".weight";
+            if ((rc = need(m, name, {HID, Lc}, &t))) return rc;
+            for (int nt = 0; nt < Lc / 32; ++nt)
+                for (int jl = 0; jl < HID / 8; ++jl)
+                    for (int l = 0; l < 64; ++l)
+                        for (int r = 0; r < 4; ++r) {
+                            const int c = 32 * nt + (l & 31), f = 8 * jl + 4 * (l >> 5) + r;
+                            plan.blob[off + (((size_t)nt * Jc + b * (HID / 8) + jl) * 64 + l) * 4 + r] = t->data[(size_t)f * Lc + c];
+                        }
+            m->repack.push_back({PACK_NTT, name, "", off + (size_t)b * (HID / 8) * 64 * 4, nullptr, Lc, HID, Kc, 0});
+        }
+        plan.fix.push_back({&wt.wzT_cat, off});
+    }
     if (d.d_out > D_IN_PAD) return fail(PNY_ERR_ARG, "d_out > 64");
     if ((rc = plain(pre + "lin_in.weight", {HID, d_in}, &wt.w_in_plain))) return rc;
     if ((rc = packedT(pre + "lin_out.weight", d.d_out, HID, &wt.wT_out))) return rc;
@@ -374,6 +396,8 @@ int pny_model_refresh(pny_model* m, pny_stream stream) {
                 j.count = (e.n_out / 32) * (e.k_pad / 8) * 64;       // 16-byte elements
             else if (e.kind == PACK_AT)
                 j.count = (e.k_in / 32) * (e.k_pad / 8) * 64;
+            else if (e.kind == PACK_NTT)
+                j.count = (e.n_out / 32) * (e.k_in / 8) * 64;
             else
                 j.count = e.count;
             max_elems = std::max(max_elems, (long long)j.count);

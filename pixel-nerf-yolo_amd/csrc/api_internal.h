@@ -99,6 +99,7 @@ struct MlpWeightsT {
     const float* wT_out;
     const float* wT_fc0[MAX_BLOCKS];
     const float* wT_fc1[MAX_BLOCKS];
+    const float* wzT_cat;     // [lin_z[0]^T | lin_z[1]^T | ...] (d_latent x n_view_blocks * 512), n-tile-major (latent_grad.hip)
     const float* h2_in;       // split-f16 images (mlp_h2.hip)
     const float* h2_fc0[MAX_BLOCKS];
     const float* h2_fc1[MAX_BLOCKS];
@@ -159,6 +160,7 @@ struct pny_scene {
     bool zp_valid[2] = {false, false};
     uint64_t zp_generation = 0;
     int zp_mode = PNY_PROJECTION_AUTO;
+    float* latent_grad = nullptr;   // (ns, hl, wl, L) caller-owned accumulator of d loss / d latent (pny_scene_bind_latent_grad)
     int precision = PNY_PRECISION_AUTO;   // matrix arithmetic of projected launches (pny_scene_set_precision)
     bool last_f16x2 = false;
     bool last_projected = false;

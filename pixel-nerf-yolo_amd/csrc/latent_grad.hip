@@ -1,0 +1,129 @@
+// Gradient w.r.t. the latent (the backward of encoder.py:101 F.grid_sample composed with lin_z; SURVEY.md 8f rank 1,
+// "(+ grid_sample)"): what autograd adds to `latent.grad` in the reference when the encoder trains.
+//
+//   forward:   h_in(b)[s, v] += lin_z[b]( sum_k w_k(s, v) . latent[v][pix_k(s, v)] )            (resnetfc.py:176-182)
+//   backward:  dlatent[v][pix_k(s, v)][c] += w_k(s, v) . dz[s, v][c],   dz[s, v] = sum_b lin_z[b]^T . dh_in(b)[s, v]
+//
+// One kernel per (64-sample tile, view): dz as a tiled fp32-MFMA GEMM straight off the dY stash -- the dX chain
+// (mlp_bwd.hip) has left dh_in(b) there in [feature/4][sample] float4 tiles, which IS the LDS B-operand layout of
+// pixel_linear_kernel (encoder.hip), so staging is a plain copy -- with K = n_view_blocks x 512 and the stacked transposed
+// weights [lin_z[0]^T | lin_z[1]^T | ...] as the packed A operand (api.hip pack_mlp, kept current by pny_model_refresh);
+// the epilogue scatters each accumulator quad (4 consecutive latent channels of one sample) into the sample's four taps
+// with float atomics.  The sum order over samples is therefore not fixed: latent gradients are reproducible to fp32
+// rounding, not bit for bit (the MLP parameter gradients stay deterministic).
+// A workgroup (4 waves) owns 64 samples x 256 latent channels, a wave 64 x 64 (2 x 2 tiles of 32 x 32).
+#include "mlp_core.h"
+
+namespace pny {
+
+constexpr int LG_KC = 32, LG_NW = 4;
+
+__global__ __launch_bounds__(64 * LG_NW) void latent_grad_kernel(const MlpArgs a, const float* __restrict__ dy_stash, const StashLayout lay,
+                                                                 const float* __restrict__ w_cat, float* __restrict__ grad, int nvb) {
+    __shared__ float4 bt[2][LG_KC / 4][64 + 1];
+    __shared__ int tap_off[64][4];
+    __shared__ float tap_w[64][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = lane & 31, hh = lane >> 5;
+    const int nblocks = a.L / 256;
+    const int nb = blockIdx.x % nblocks;
+    const long long tv = blockIdx.x / nblocks;
+    const int v = (int)(tv % a.NS);
+    const long long tile = tv / a.NS;
+    const int K = nvb * HID, J = K / 8;
+    if (tid < 64) {
+        long long s = tile * 64 + tid;
+        int offs[4];
+        float wgt[4];
+        const bool live = s < a.n_points;
+        if (!live) s = a.n_points - 1;
+        sample_taps(a, v, s, offs, wgt);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            tap_off[tid][k] = offs[k];
+            tap_w[tid][k] = live ? wgt[k] : 0.0f;
+        }
+    }
+    // B operand: chunk c = 32 features of block c / 16; the stash slot of dh_in(b) is (2 b + 1) slots into the view's part
+    const float* dyv = dy_stash + tile * lay.dy_tile + (size_t)v * lay.dy_view;
+    auto stage_load = [&](int c, float4 (&sv)[2]) {
+        const int b = c / (HID / LG_KC), kg0 = (c % (HID / LG_KC)) * (LG_KC / 4);
+        const float4* src = reinterpret_cast<const float4*>(dyv + (size_t)(2 * b + 1) * STASH_SLOT) + (size_t)kg0 * 64;
+        sv[0] = src[tid];
+        sv[1] = src[tid + 256];
+    };
+    auto stage_store = [&](int buf, const float4 (&sv)[2]) {
+        bt[buf][tid >> 6][tid & 63] = sv[0];
+        bt[buf][4 + (tid >> 6)][tid & 63] = sv[1];
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.f;
+    const int nt0 = nb * 8 + wave * 2;
+    const float4* wp = reinterpret_cast<const float4*>(w_cat) + (size_t)nt0 * J * 64 + lane;
+    const int nchunks = K / LG_KC;
+    float4 sv[2];
+    stage_load(0, sv);
+    stage_store(0, sv);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) stage_load(c + 1, sv);
+        float4 wa[LG_KC / 8][2];
+#pragma unroll
+        for (int j = 0; j < LG_KC / 8; ++j)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) wa[j][nt] = wp[((size_t)nt * J + (size_t)c * (LG_KC / 8) + j) * 64];
+#pragma unroll
+        for (int j = 0; j < LG_KC / 8; ++j) {
+            float4 b[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) b[mt] = bt[buf][2 * j + hh][32 * mt + m0];
+#define PNY_STEP(cc)                                                                          \
+    _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                          \
+        _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                      \
+            acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j][nt].cc, b[mt].cc, acc[nt][mt], 0, 0, 0);
+            PNY_STEP(x)
+            PNY_STEP(y)
+            PNY_STEP(z)
+            PNY_STEP(w)
+#undef PNY_STEP
+        }
+        if (c + 1 < nchunks) {
+            stage_store(buf ^ 1, sv);
+            __syncthreads();
+        }
+    }
+    // scatter: accumulator quad (nt, q) of lane (m0, hh), tile mt = latent channels 32 (nt0 + nt) + 8 q + 4 hh + 0..3 of sample 32 mt + m0
+    float* gv = grad + (size_t)v * a.Hl * a.Wl * a.L;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int m = 32 * mt + m0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float wk = tap_w[m][k];
+            if (wk == 0.0f) continue;
+            float* gp = gv + tap_off[m][k];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = 32 * (nt0 + nt) + 8 * q + 4 * hh;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) unsafeAtomicAdd(gp + n + r, wk * acc[nt][mt][4 * q + r]);
+                }
+        }
+    }
+}
+
+void launch_latent_grad(const MlpArgs& a, const float* dy_stash, const StashLayout& lay, const float* w_cat, float* grad, int nvb,
+                        hipStream_t st) {
+    const long long blocks = (long long)a.n_tiles * a.NS * (a.L / 256);
+    hipLaunchKernelGGL(latent_grad_kernel, dim3((unsigned)blocks), dim3(64 * LG_NW), 0, st, a, dy_stash, lay, w_cat, grad, nvb);
+}
+
+}  // namespace pny

@@ -577,6 +577,51 @@ __device__ __forceinline__ void prologue(const MlpArgs& a, int v, long long tile
     }
 }
 
+// The four bilinear taps of sample s in source view v: element offsets (pixel index x tap_stride) and weights, exactly as
+// the prologue above computes them (projection models.py:219-230; grid_sample coordinates encoder.py:97-98,
+// align_corners=True, zeros padding; YOLO-mode culling).  Used by kernels outside the forward chain (latent_grad.hip).
+__device__ __forceinline__ void sample_taps(const MlpArgs& a, int v, long long s, int (&offs)[4], float (&wgt)[4]) {
+    float p[3], d[3];
+    load_point(a, s, p, d);
+    const Cam cam = a.cams[v];
+    float xc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        xc[i] = (cam.w2c[4 * i + 0] * p[0] + cam.w2c[4 * i + 1] * p[1] + cam.w2c[4 * i + 2] * p[2]) + cam.w2c[4 * i + 3];
+    float ux, uy;
+    if (!a.yolo) {
+        ux = -xc[0] / xc[2];
+        uy = -xc[1] / xc[2];
+    } else {
+        ux = xc[0] / xc[2];
+        uy = xc[1] / xc[2];
+    }
+    ux = ux * cam.fx + cam.cx;
+    uy = uy * cam.fy + cam.cy;
+    const float gx = ux * a.sx - 1.0f, gy = uy * a.sy - 1.0f;
+    const float ix = ((gx + 1.0f) / 2.0f) * (float)(a.Wl - 1);
+    const float iy = ((gy + 1.0f) / 2.0f) * (float)(a.Hl - 1);
+    const float x0 = floorf(ix), y0 = floorf(iy);
+    const float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
+    wgt[0] = (x1 - ix) * (y1 - iy);
+    wgt[1] = (ix - x0) * (y1 - iy);
+    wgt[2] = (x1 - ix) * (iy - y0);
+    wgt[3] = (ix - x0) * (iy - y0);
+    const float xs[4] = {x0, x1, x0, x1};
+    const float ys[4] = {y0, y0, y1, y1};
+    const bool cull = a.yolo && !(xc[2] < 0.0f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool ok = (xs[k] >= 0.f) && (xs[k] <= (float)(a.Wl - 1)) && (ys[k] >= 0.f) && (ys[k] <= (float)(a.Hl - 1));
+        offs[k] = 0;
+        if (ok)
+            offs[k] = ((int)ys[k] * a.Wl + (int)xs[k]) * a.tap_stride;
+        else
+            wgt[k] = wgt[k] * 0.0f;
+        if (cull || (a.yolo && (wgt[k] != wgt[k]))) wgt[k] = 0.0f;
+    }
+}
+
 // Bilinear gather of the latent (reference encoder.py:101 F.grid_sample, written tap by tap) into the
 // B-operand layout act[(c - c0)/4][m], pipelined with the lin_z GEMM in chunks of GCH channels:
 // gather_issue() starts the 16-byte tap loads of a chunk into registers, gather_commit() combines

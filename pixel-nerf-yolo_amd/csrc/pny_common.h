@@ -95,7 +95,7 @@ struct MlpArgs {
 };
 
 // ---- device-side weight repack (pack.hip): the packed operand layouts rebuilt from the live parameter tensors
-enum { PACK_A = 0, PACK_AT = 1, PACK_NT = 2, PACK_COPY = 3, PACK_ADD2 = 4, PACK_H2 = 5 };
+enum { PACK_A = 0, PACK_AT = 1, PACK_NT = 2, PACK_COPY = 3, PACK_ADD2 = 4, PACK_H2 = 5, PACK_NTT = 6 };
 struct PackJob {
     const float* src;
     const float* src2;
@@ -183,6 +183,9 @@ enum { MLP_8x64 = 0, MLP_16x64 = 1, MLP_8x32 = 2 };  // kernel shapes (mlp.hip C
 int mlp_pick_variant(long long n_points);           // shape for a launch of n_points samples
 void launch_mlp(const MlpArgs& a, int variant, int grid, hipStream_t st);
 void launch_mlp_stash(const MlpArgs& a, int grid, hipStream_t st);  // 8x64 shape, reference op order, writes a.stash_x
+// latent gradient (latent_grad.hip): a.tap_stride must be a.L; grad is (NS, Hl, Wl, L) channel-last, added into
+void launch_latent_grad(const MlpArgs& a, const float* dy_stash, const StashLayout& lay, const float* w_cat, float* grad, int nvb,
+                        hipStream_t st);
 bool mlp_h2_supports(int n_blocks, int combine_layer);
 void launch_mlp_h2(const MlpArgs& a, int grid, hipStream_t st);     // 8x64 shape, projected latent, split-f16 operands (mlp_h2.hip)
 int mlp_max_grid(int variant);      // resident workgroups = persistent grid size

@@ -367,6 +367,13 @@ int mlp_backward(pny_scene* s, int mode, const float* xyz, const float* dirs, co
             launch_mlp_dz(dz, st);
             PNY_HIP(hipGetLastError());
         }
+        // 2c. gradient w.r.t. the latent (encoder training): lin_z^T GEMM off the dY stash + scatter into the taps
+        if (s->latent_grad && view_blocks(d) > 0) {
+            if (!wt.wzT_cat) return fail(PNY_ERR_STATE, "latent gradient: transposed lin_z weights are missing");
+            if (s->L % 256) return fail(PNY_ERR_ARG, "latent gradient: d_latent must be a multiple of 256");
+            launch_latent_grad(a, dy_base, plan.lay, wt.wzT_cat, s->latent_grad, view_blocks(d), st);
+            PNY_HIP(hipGetLastError());
+        }
         // 3. weight-gradient GEMMs over the two stashes + deterministic split reduction into the bound gradients
         if (!defer && !have_x &&
             (rc = run_weight_grads(m, plan, n_tiles, x_base, dy_base, s->dw_partial, s->dw_bias, s->dw_tables, s->table_stage,
@@ -380,6 +387,12 @@ int mlp_backward(pny_scene* s, int mode, const float* xyz, const float* dirs, co
 }  // namespace
 
 extern "C" {
+
+int pny_scene_bind_latent_grad(pny_scene* s, float* grad_dev) {
+    if (!s) return fail(PNY_ERR_ARG, "pny_scene_bind_latent_grad: null scene");
+    s->latent_grad = grad_dev;
+    return PNY_OK;
+}
 
 int pny_model_bind_grad(pny_model* m, const char* name, float* grad_dev) {
     if (!m || !name) return fail(PNY_ERR_ARG, "pny_model_bind_grad: null argument");

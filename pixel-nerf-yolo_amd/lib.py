@@ -95,6 +95,7 @@ SIGNATURES = {
                                C.c_void_p, C.c_void_p]),
     "pny_scene_set_projection": (C.c_int, [C.c_void_p, C.c_int]),
     "pny_scene_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
+    "pny_scene_bind_latent_grad": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pny_scene_last_precision": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "pny_scene_project": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pny_scene_last_mlp_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -116,7 +117,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 7
+ABI_VERSION = 8
 PROJECTION = {"off": 0, "on": 1, "auto": 2}
 PRECISION = {"f32": 0, "f16x2": 1, "auto": 2}
 

@@ -426,6 +426,28 @@ class PixelNeRFNet(nn.Module):
                 "libpnyolo differentiates the MLPs only: freeze the encoder (make_model(conf, stop_encoder_grad=True) "
                 "or requires_grad_(False) on net.encoder, as the reference's --freeze_enc does)")
 
+    def differentiable_latent(self):
+        """The latent tensor of the last encode(latent=...) if it requires grad and autograd is recording in train() mode
+        (the render / query backward then returns d loss / d latent for it), else None."""
+        if torch.is_grad_enabled() and self.training:
+            return getattr(self, "_latent_src", None)
+        return None
+
+    def begin_latent_grad(self, meta, n_scenes):
+        """Zeroed (SB * NS, Hl, Wl, L) accumulator bound slice by slice to the scenes (pny_scene_bind_latent_grad)."""
+        n_lat, l_ch, hl, wl = meta[0]
+        buf = torch.zeros(n_lat, hl, wl, l_ch, device=self._device(), dtype=torch.float32)
+        nsv = n_lat // n_scenes
+        for sb in range(n_scenes):
+            check(_lib.load().pny_scene_bind_latent_grad(self._scene(sb), ptr(buf[sb * nsv:(sb + 1) * nsv])))
+        return buf
+
+    def end_latent_grad(self, buf, meta, n_scenes):
+        """Unbind and return the gradient in the latent's own layout (SB * NS, L, Hl, Wl), device and dtype."""
+        for sb in range(n_scenes):
+            check(_lib.load().pny_scene_bind_latent_grad(self._scene(sb), None))
+        return buf.permute(0, 3, 1, 2).to(meta[1], meta[2])
+
     def bind_mlp_grads(self):
         """Fresh zeroed gradient buffers for trainable_mlp_parameters(), bound to the native model by name
         (pny_model_bind_grad); returns them in the same order."""
@@ -514,6 +536,9 @@ class PixelNeRFNet(nn.Module):
         if latent is None and self.encoder.use_custom_resnet:
             raise RuntimeError("backbone=custom (YOLOv7) has no kernels in this build (its source and weights are "
                                "outside the reference tree): pass the backbone output via encode(..., latent=...)")
+        # a latent that requires grad (produced by a trainable encoder outside the library): the render backward returns
+        # d loss / d latent for it (render._RenderFunction, pny_scene_bind_latent_grad)
+        self._latent_src = latent if (torch.is_tensor(latent) and latent.requires_grad) else None
         if latent is not None:
             latent = latent.detach().to(dev, torch.float32).contiguous()
             assert latent.dim() == 4 and latent.shape[0] == SB * NS, "latent must be (SB*NS, L, Hl, Wl)"
@@ -564,9 +589,13 @@ class PixelNeRFNet(nn.Module):
             raise RuntimeError("libpnyolo does not differentiate w.r.t. the query points: detach xyz")
         # autograd path in train() mode only: eval-mode calls outside no_grad (the reference's eval scripts are not
         # consistent about it) return plain tensors, as before
-        if torch.is_grad_enabled() and self.training and self.trainable_mlp_parameters():
-            self.check_differentiable()
-            return _QueryFunction.apply(self, xyz, bool(coarse), viewdirs, *[p for _, p in self.trainable_mlp_parameters()])
+        if torch.is_grad_enabled() and self.training:
+            params, lat = self.trainable_mlp_parameters(), self.differentiable_latent()
+            if params or lat is not None:
+                if lat is None:
+                    self.check_differentiable()
+                return _QueryFunction.apply(self, xyz, bool(coarse), viewdirs, len(params), *[p for _, p in params],
+                                            *([lat] if lat is not None else []))
         return self._query(xyz, coarse, viewdirs)
 
     def _query(self, xyz, coarse, viewdirs):
@@ -630,7 +659,9 @@ class _QueryFunction(torch.autograd.Function):
     """PixelNeRFNet.forward under autograd: pny_query forward, pny_query_backward into bound gradient buffers."""
 
     @staticmethod
-    def forward(ctx, net, xyz, coarse, viewdirs, *params):
+    def forward(ctx, net, xyz, coarse, viewdirs, n_params, *params):
+        lat = params[n_params] if len(params) > n_params else None
+        ctx.lat_meta = None if lat is None else (tuple(lat.shape), lat.device, lat.dtype)
         out = net._query(xyz, coarse, viewdirs)
         dev = net._device()
         ctx.net, ctx.coarse = net, coarse
@@ -647,10 +678,13 @@ class _QueryFunction(torch.autograd.Function):
         g_out = g_out.detach().to(dev, torch.float32).contiguous()
         use_coarse = bool(ctx.coarse) or net.mlp_fine is None
         st = stream_of(dev)
-        for sb in range(ctx.xyz.shape[0]):
+        SB = ctx.xyz.shape[0]
+        lat_grad = net.begin_latent_grad(ctx.lat_meta, SB) if ctx.lat_meta is not None else None
+        for sb in range(SB):
             check(L.pny_query_backward(net._scene(sb), ptr(ctx.xyz[sb]), ptr(ctx.dirs[sb]), ctx.xyz.shape[1], int(use_coarse),
                                        ptr(g_out[sb]), 1, st))
-        return (None, None, None, None) + tuple(grads)
+        extra = () if lat_grad is None else (net.end_latent_grad(lat_grad, ctx.lat_meta, SB),)
+        return (None, None, None, None, None) + tuple(grads) + extra
 
 
 def make_model(conf, *args, **kwargs):

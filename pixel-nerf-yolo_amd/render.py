@@ -47,6 +47,9 @@ class _RenderFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, renderer, model, rays, has_fine, n_params, *params):
+        # params = the trainable MLP parameters, optionally followed by the differentiable latent of encode(latent=...)
+        lat = params[n_params] if len(params) > n_params else None
+        ctx.lat_meta = None if lat is None else (tuple(lat.shape), lat.device, lat.dtype)
         # Reserve the model-level stash for every scene's tiles (pny_model_defer_weight_grads): the forward then writes the
         # GEMM operands the backward needs while it evaluates the MLPs (no recompute), the scenes' backward calls run on
         # side streams and ONE weight-gradient GEMM per MLP follows.  If the reservation exceeds the stash budget: plain
@@ -96,6 +99,8 @@ class _RenderFunction(torch.autograd.Function):
         deferred = ctx.deferred and getattr(model, "_defer_token", None) == ctx.token
         acc = 1 if deferred else 3
         streams = model.fork_streams(SB) if deferred else [None] * SB
+        # d loss / d latent, accumulated by every scene's call into its own slice (channel-last)
+        lat_grad = model.begin_latent_grad(ctx.lat_meta, SB) if ctx.lat_meta is not None else None
         for sb in range(SB):
             with torch.cuda.stream(streams[sb]):
                 s_ = _lib.RenderSaved(z_coarse=sv["z_coarse"][sb].data_ptr(), sample_coarse=sv["sample_coarse"][sb].data_ptr())
@@ -111,7 +116,8 @@ class _RenderFunction(torch.autograd.Function):
             model.join_streams(streams)
             check(L.pny_model_flush_weight_grads(model._h_model, 1, stream_of(dev)))
             check(L.pny_model_defer_weight_grads(model._h_model, 0, 0, 0, 0))
-        return (None, None, None, None, None) + tuple(grads)
+        extra = () if lat_grad is None else (model.end_latent_grad(lat_grad, ctx.lat_meta, SB),)
+        return (None, None, None, None, None) + tuple(grads) + extra
 
 
 class NeRFRenderer(torch.nn.Module):
@@ -152,13 +158,17 @@ class NeRFRenderer(torch.nn.Module):
             self.n_coarse = self.sched[1][self.last_sched.item() - 1]
             self.n_fine = self.sched[2][self.last_sched.item() - 1]
         assert len(rays.shape) == 3
-        params = model.trainable_mlp_parameters() if (torch.is_grad_enabled() and model.training) else []
-        if not params:
+        grad_mode = torch.is_grad_enabled() and model.training
+        params = model.trainable_mlp_parameters() if grad_mode else []
+        lat_src = model.differentiable_latent()
+        if not params and lat_src is None:
             res, _ = self._render(model, rays, want_weights, save=False)
             return res
-        model.check_differentiable()
+        if lat_src is None:
+            model.check_differentiable()     # (with a differentiable latent the caller's own encoder takes the gradient)
         kf = int(self.n_fine) if (self.using_fine and self.n_fine > 0) else 0
-        outs = _RenderFunction.apply(self, model, rays, kf > 0, len(params), *[p for _, p in params])
+        outs = _RenderFunction.apply(self, model, rays, kf > 0, len(params), *[p for _, p in params],
+                                     *([lat_src] if lat_src is not None else []))
         res = {"coarse": {"rgb": outs[0], "depth": outs[1]}}
         if want_weights:
             res["coarse"]["weights"] = outs[2]
@@ -324,9 +334,11 @@ class YoloRenderer(torch.nn.Module):
         grad mode on) the result carries a graph: backward = pny_yolo_render_backward (YoloTrainer.py:160-186)."""
         net = self.net
         params = net.trainable_mlp_parameters() if (torch.is_grad_enabled() and net.training) else []
-        if params:
-            net.check_differentiable()
-            return _YoloRenderFunction.apply(self, rays, *[p for _, p in params])
+        lat = net.differentiable_latent()
+        if params or lat is not None:
+            if lat is None:
+                net.check_differentiable()
+            return _YoloRenderFunction.apply(self, rays, len(params), *[p for _, p in params], *([lat] if lat is not None else []))
         return self._render(rays)[0]
 
     def _render(self, rays, keep_raw=False):
@@ -364,7 +376,9 @@ class _YoloRenderFunction(torch.autograd.Function):
     pny_yolo_render_backward into gradient buffers bound to the parameters of mlp_coarse."""
 
     @staticmethod
-    def forward(ctx, renderer, rays, *params):
+    def forward(ctx, renderer, rays, n_params, *params):
+        lat = params[n_params] if len(params) > n_params else None
+        ctx.lat_meta = None if lat is None else (tuple(lat.shape), lat.device, lat.dtype)
         out, saved = renderer._render(rays, keep_raw=True)
         ctx.renderer, ctx.saved = renderer, saved
         return out
@@ -376,9 +390,11 @@ class _YoloRenderFunction(torch.autograd.Function):
         dev = net._device()
         grads = net.bind_mlp_grads()
         g_out = g_out.detach().to(dev, torch.float32).contiguous()
+        lat_grad = net.begin_latent_grad(ctx.lat_meta, 1) if ctx.lat_meta is not None else None
         check(L.pny_yolo_render_backward(net._scene(0), ptr(sv["rays"]), sv["rays"].shape[0], sv["n_coarse"], ptr(sv["u"]),
                                          sv["seed"], ptr(sv["raw"]), ptr(g_out), 1, stream_of(dev)))
-        return (None, None) + tuple(grads)
+        extra = () if lat_grad is None else (net.end_latent_grad(lat_grad, ctx.lat_meta, 1),)
+        return (None, None, None) + tuple(grads) + extra
 
 
 def make_renderer(conf, lindisp=False):

@@ -105,8 +105,9 @@ def clean_rays(sc, rays, kc, kf, kfd, draws, n, **kw):
 
 
 # --------------------------------------------------------------------------- MLP (query) backward
-def scene_pair(ns, H, W, L, d_out, n_blocks, combine_layer, seed, yolo=False, lat_hw=None):
-    """The same seeded scene as a HIP net (trainable MLP, frozen encoder) and as oracle state with requires_grad."""
+def scene_pair(ns, H, W, L, d_out, n_blocks, combine_layer, seed, yolo=False, lat_hw=None, lat_grad=False):
+    """The same seeded scene as a HIP net (trainable MLP, frozen encoder) and as oracle state with requires_grad.
+    lat_grad: the latent is a leaf that requires grad on both sides (net.test_latent on the GPU, sc.latent on the CPU)."""
     c = pconf.yolo() if yolo else pconf.default_mv()
     m = c.d["model"]
     if L != 512 and not yolo:
@@ -132,11 +133,14 @@ def scene_pair(ns, H, W, L, d_out, n_blocks, combine_layer, seed, yolo=False, la
     else:
         poses, _ = synth.scene_cameras(ns)
         focal, cc = torch.tensor(0.9 * W), torch.tensor([[W * 0.5, H * 0.5]])
-    net.encode(torch.zeros(1, ns, 3, H, W), torch.from_numpy(poses)[None], focal, c=cc, latent=torch.from_numpy(lat))
+    net.test_latent = torch.from_numpy(lat).to(DEV).requires_grad_() if lat_grad else torch.from_numpy(lat)
+    net.encode(torch.zeros(1, ns, 3, H, W), torch.from_numpy(poses)[None], focal, c=cc, latent=net.test_latent)
     mc = {k: torch.from_numpy(v).requires_grad_() for k, v in sd_c.items()}
     mf = None if sd_f is None else {k: torch.from_numpy(v).requires_grad_() for k, v in sd_f.items()}
     sc = orc.Scene(mc, mf, lat, poses, focal, cc, W, H, yolo=yolo, n_blocks=n_blocks, combine_layer=combine_layer)
     sc.mlp_coarse, sc.mlp_fine = mc, mf          # Scene() re-wraps tensors: keep the leaves
+    if lat_grad:
+        sc.latent = torch.from_numpy(lat).requires_grad_()
     return net, sc
 
 
@@ -244,6 +248,44 @@ def test_render_backward_vs_oracle(with_depth, detach):
     assert int(((zd > 0.3) & (zd < 1.8)).sum()) > n * kfd // 2        # most depth samples are unclamped
     render_loss(ref, gt, with_depth).backward()
     compare_param_grads(net, sc)
+
+
+@pytest.mark.parametrize("L,frozen_mlp", [(512, False), (512, True), (1792, False)])
+def test_latent_gradient_vs_oracle_autograd(L, frozen_mlp):
+    """d loss / d latent through the renderer (the backward of encoder.py:101 grid_sample composed with lin_z): the latent
+    handed to encode(latent=...) requires grad, loss.backward() fills its .grad -- compared with torch.autograd through the
+    oracle on the same rays and draws, together with the MLP parameter gradients of the same backward (or alone, with the
+    MLPs frozen).  Depth samples attached (the reference's graph)."""
+    ns, H, W, kc, kf, kfd, n = 2, 32, 32, 16, 8, 4, 40
+    net, sc = scene_pair(ns, H, W, L, 4, 5, 3, 730, lat_hw=(16, 16), lat_grad=True)
+    lat_hip, lat_ref = net.test_latent, sc.latent
+    _, tgt = synth.scene_cameras(ns)
+    if frozen_mlp:
+        for p in list(net.mlp_coarse.parameters()) + list(net.mlp_fine.parameters()):
+            p.requires_grad_(False)
+    rs = np.random.RandomState(11)
+    nc = H * W
+    rays = orc.gen_rays(tgt[None], W, H, 0.9 * W, 0.3, 1.8)[0].reshape(-1, 8)
+    dr = dict(u_coarse=rs.rand(nc, kc).astype(np.float32), u_fine=rs.rand(nc, kf - kfd).astype(np.float32),
+              u_fine2=rs.rand(nc, kf - kfd).astype(np.float32), g_depth=rs.randn(nc, kfd).astype(np.float32))
+    keep = clean_rays(sc, rays, kc, kf, kfd, dr, n)
+    rays, dr = rays[torch.from_numpy(keep)], {k: v[keep] for k, v in dr.items()}
+    gt = torch.from_numpy(rs.uniform(0, 1, size=(n, 3)).astype(np.float32))
+    ren = NeRFRenderer(n_coarse=kc, n_fine=kf, n_fine_depth=kfd, white_bkgd=True).train()
+    ren.draws = dr
+    out = ren(net, rays[None].to(DEV), want_weights=True)
+    assert out["fine"]["rgb"].requires_grad
+    hip = {p: {k: v[0] for k, v in out[p].items()} for p in ("coarse", "fine")}
+    render_loss(hip, gt.to(DEV), True).backward()
+    ref = orc.render(sc, rays, kc, kf, kfd, dr["u_coarse"], dr["u_fine"], dr["u_fine2"], dr["g_depth"])
+    render_loss(ref, gt, True).backward()
+    assert lat_hip.grad is not None and lat_hip.grad.shape == lat_ref.grad.shape
+    assert float(lat_ref.grad.abs().max()) > 0
+    grad_check("latent", lat_hip.grad, lat_ref.grad)
+    if not frozen_mlp:
+        compare_param_grads(net, sc)
+    else:
+        assert all(p.grad is None for p in net.mlp_coarse.parameters())
 
 
 def test_training_step_updates_weights():
@@ -476,6 +518,53 @@ def test_yolo_render_backward_vs_oracle():
     ref = orc.yolo_render(sc, rays, K, u)
     assert maxabs(out, ref["out"].detach()) < 1e-4 * max(1.0, float(ref["out"].detach().abs().max()))
     (ref["out"] * G).sum().backward()
+    compare_param_grads(net, sc, which=("mlp_coarse",))
+
+
+def test_latent_gradient_yolo_render_and_query():
+    """The same gradient through the other two autograd entry points: YoloRenderer (the fork's training path: the latent comes
+    from the YOLOv7 backbone, L = 1792, culled taps contribute nothing) and PixelNeRFNet.forward (query)."""
+    from pixel_nerf_yolo_amd.render import YoloRenderer
+    n, K = 30, 32
+    net, sc = scene_pair(2, 64, 64, 1792, 21, 5, 3, 1500, yolo=True, lat_hw=(8, 8), lat_grad=True)
+    _, tgt_c2w = synth.scene_cameras(2, radius=4.0, phi=-25.0)
+    flipyz = np.diag([1.0, -1.0, -1.0, 1.0]).astype(np.float32)
+    tgt_w2c = np.linalg.inv(tgt_c2w @ flipyz).astype(np.float32)
+    cand = orc.gen_rays_yolo(tgt_w2c[None], 16, 12, [5.0, 5.5], [8.0, 6.0], 1.0, 6.0)[0].reshape(-1, 8)
+    rs = np.random.RandomState(22)
+    u_all = rs.rand(cand.shape[0], K).astype(np.float32)
+    orc.RELU_TRACE = []
+    with torch.no_grad():
+        orc.yolo_render(sc, cand, K, u_all)
+    ok = torch.ones(cand.shape[0], dtype=torch.bool)
+    for t in orc.RELU_TRACE:
+        ok &= t.reshape(cand.shape[0], -1).min(dim=1)[0] >= AMBIG
+    orc.RELU_TRACE = None
+    keep = ok.nonzero().flatten()[:n]
+    assert keep.numel() == n, int(ok.sum())
+    rays, u = cand[keep], u_all[keep.numpy()]
+    G = torch.from_numpy(rs.standard_normal((n, 3, 7)).astype(np.float32))
+    ren = YoloRenderer(K, 128, 1, 3)
+    ren.bind_parallel(net)
+    ren.draws = dict(u_coarse=u)
+    out = ren(rays[None].to(DEV))
+    (out * G.to(DEV)).sum().backward()
+    ref = orc.yolo_render(sc, rays, K, u)
+    (ref["out"] * G).sum().backward()
+    assert float(sc.latent.grad.abs().max()) > 0
+    grad_check("latent (yolo render)", net.test_latent.grad, sc.latent.grad)
+    compare_param_grads(net, sc, which=("mlp_coarse",))
+    # query
+    net, sc = scene_pair(3, 32, 40, 512, 4, 5, 3, 560, lat_grad=True)
+    xyz = rs.uniform(-0.5, 0.5, size=(120, 3)).astype(np.float32)
+    vd = rs.standard_normal((120, 3)).astype(np.float32)
+    keep = clean_points(sc, xyz, vd, 48)
+    xyz, vd = xyz[keep], vd[keep]
+    G = rs.standard_normal((48, 4)).astype(np.float32)
+    out = net(dt(xyz)[None], coarse=True, viewdirs=dt(vd)[None])
+    (out[0] * dt(G)).sum().backward()
+    (orc.query(sc, xyz, vd, coarse=True) * torch.from_numpy(G)).sum().backward()
+    grad_check("latent (query)", net.test_latent.grad, sc.latent.grad)
     compare_param_grads(net, sc, which=("mlp_coarse",))
 
 
