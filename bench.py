@@ -145,16 +145,17 @@ def train_main(args):
             dist.init_process_group("nccl", device_id=dev)
     SB, NSV, H, W, RB, KC, KF, KFD = 4, NS, 128, 128, 128, 64, 32, 16
     steps = args.steps if args.steps is not None else 10
-    net = make_model(pconf.default_mv()["model"], stop_encoder_grad=True)
+    net = make_model(pconf.default_mv()["model"], stop_encoder_grad=not args.train_encoder)
     sd = {}
     sd.update({"mlp_coarse." + k: v for k, v in synth.mlp_state(71).items()})
     sd.update({"mlp_fine." + k: v for k, v in synth.mlp_state(72).items()})
     sd.update(synth.resnet34_state(74, residual_gain=0.25))
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
     net = net.to(dev).train()
-    net.encoder.eval()                                             # train.py:70-73 (--freeze_enc)
-    for p_ in net.encoder.parameters():
-        p_.requires_grad_(False)
+    if not args.train_encoder:
+        net.encoder.eval()                                         # train.py:70-73 (--freeze_enc)
+        for p_ in net.encoder.parameters():
+            p_.requires_grad_(False)
     ren = NeRFRenderer(n_coarse=KC, n_fine=KF, n_fine_depth=KFD, depth_std=0.01, white_bkgd=True).train()
     par = ren.bind_parallel(net, None).train()
     opt = torch.optim.Adam([p_ for p_ in net.parameters() if p_.requires_grad], lr=1e-4)
@@ -219,8 +220,10 @@ def train_main(args):
         "metric": "training rays/sec, 64+32 samples/ray, 3-view 128x128 conditioning", "value": world * SB * RB * steps / elapsed,
         "unit": "rays/s", "n_gpus": world, "n_ranks_seen": dist.get_world_size() if dist.is_initialized() else 1, "steps": steps, "warmup": max(args.warmup, 2), "ms_per_step": elapsed / steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "train step of the C2 model: SB=4 objects x 3 views 128x128 (frozen ResNet34 trunk encoded "
-                               "every step), 128 rays/object, 64 coarse + 32 fine (16 depth), MSE coarse+fine, Adam",
+        "config": {"workload": "train step of the C2 model: SB=4 objects x 3 views 128x128 (%s), 128 rays/object, 64 coarse + "
+                               "32 fine (16 depth), MSE coarse+fine, Adam" % (
+                                   "ResNet34 trunk TRAINED: torch graph forward / backward + latent-gradient kernel"
+                                   if args.train_encoder else "frozen ResNet34 trunk encoded every step"),
                    "rays_per_step": world * SB * RB, "rays_per_step_this_rank": SB * RB,
                    "parallelism": "dp%d: one super-batch per rank, 1 gradient all-reduce (27 MB fp32) per step" % world},
         "loss_first": float(l0), "loss_last": float(loss),
@@ -254,6 +257,9 @@ def main():
     ap.add_argument("--precision", choices=["auto", "f32", "f16x2"], default="auto",
                     help="matrix arithmetic of projected launches (include/pnyolo.h pny_scene_set_precision)")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the --precision f32 leg of the N=1 line")
+    ap.add_argument("--train-encoder", action="store_true",
+                    help="--mode train: do not freeze the ResNet-34 trunk (the reference's default training graph): the trunk "
+                         "runs as a torch graph, the renderer returns d loss / d latent to it")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2",
                     help="c2 = BASELINE.json configs[1] (default, the bench line); c3/c4/c5 = configs[2..4]")
     ap.add_argument("--no-reference-order", action="store_true", help="skip the --projection off leg of the N=1 line")

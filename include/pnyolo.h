@@ -269,7 +269,8 @@ int pny_scene_enable_timing(pny_scene* s, int enable);
  * the dX chain and the weight-gradient GEMMs run over the stash.
  * The fine pass's depth samples depend on the coarse depth in the reference (nerf.py:156-167: no detach): that path
  * (gradient w.r.t. sample positions through the positional code, the projection and the bilinear latent lookup) is
- * included.  Not differentiated: the latent / encoder, the rays, the cameras. */
+ * included.  The latent is differentiated through pny_scene_bind_latent_grad (below); not differentiated: the encoder's
+ * convolutions (the gradient is handed to whoever produced the latent), the rays, the cameras. */
 
 /* Gradient target of the state_dict entry `name` ("mlp_coarse.blocks.2.fc_1.weight", ...): a device buffer of the
  * parameter's shape (fp32, contiguous) that the backward calls write / add into.  NULL unbinds.  Borrowed until

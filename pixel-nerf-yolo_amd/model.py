@@ -160,6 +160,32 @@ class SpatialEncoder(nn.Module):
         self.use_first_pool = use_first_pool
         self.index_interp, self.index_padding, self.upsample_interp = index_interp, index_padding, upsample_interp
 
+    def forward_torch(self, x):
+        """The trunk as a differentiable torch graph (reference encoder.py:110-173, resnet34 branch): used by
+        ``PixelNeRFNet.encode`` when the encoder TRAINS -- the library's own trunk (csrc/encoder.hip) is forward only, so the
+        convolutions and batch norms (train-mode statistics when ``self.training``) then run through ATen and autograd,
+        and the renderer's backward hands d loss / d latent back to this graph (pny_scene_bind_latent_grad)."""
+        import torch.nn.functional as F
+        if self.use_custom_resnet:
+            raise RuntimeError("backbone=custom has no trunk here: supply the latent")
+        m = self.model
+
+        def block(blk, t):
+            out = torch.relu(blk.bn1(blk.conv1(t)))
+            out = blk.bn2(blk.conv2(out))
+            return torch.relu(out + (blk.downsample(t) if hasattr(blk, "downsample") else t))
+
+        x = torch.relu(m.bn1(m.conv1(x)))
+        latents = [x]
+        if self.use_first_pool:
+            x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+        for layer in (m.layer1, m.layer2, m.layer3):
+            for blk in layer:
+                x = block(blk, x)
+            latents.append(x)
+        size = latents[0].shape[-2:]
+        return torch.cat([F.interpolate(t, size, mode="bilinear", align_corners=True) for t in latents], dim=1)
+
     @classmethod
     def from_conf(cls, conf):
         return cls(conf.get_string("backbone"), pretrained=conf.get_bool("pretrained", True),
@@ -299,9 +325,13 @@ class PixelNeRFNet(nn.Module):
             old = self._synced_key
             # Only MLP tensors changed IN PLACE (same storage, new version: an optimizer step) -> device-side refresh:
             # one kernel launch re-creates the packed operands from the live parameters (pny_model_refresh).
+            # Encoder tensors stepped in place (encoder training: the trunk then runs in torch, encode()) only mark the native
+            # trunk's copy stale; it is re-uploaded when the native trunk is next needed (_need_native_encoder).
             in_place = (old is not None and self._dev_bound and len(old) == len(key) and
-                        all(a[:2] == b[:2] and (a[2] == b[2] or a[0].startswith("mlp_")) for a, b in zip(old, key)))
+                        all(a[:2] == b[:2] and (a[2] == b[2] or a[0].startswith(("mlp_", "encoder."))) for a, b in zip(old, key)))
             if in_place:
+                if any(a[2] != b[2] and a[0].startswith("encoder.") for a, b in zip(old, key)):
+                    self._enc_stale = True
                 check(L.pny_model_refresh(h, stream_of(dev)))
             else:
                 for name, t in self.state_dict().items():
@@ -311,6 +341,7 @@ class PixelNeRFNet(nn.Module):
                     shape = (C.c_int64 * max(a.ndim, 1))(*a.shape)
                     check(L.pny_model_load_weights(h, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim))
                 check(L.pny_model_finalize(h))
+                self._enc_stale = False
                 self._dev_bound = True
                 for name, t in self.state_dict(keep_vars=True).items():
                     if name.startswith("mlp_"):
@@ -536,13 +567,21 @@ class PixelNeRFNet(nn.Module):
         if latent is None and self.encoder.use_custom_resnet:
             raise RuntimeError("backbone=custom (YOLOv7) has no kernels in this build (its source and weights are "
                                "outside the reference tree): pass the backbone output via encode(..., latent=...)")
-        # a latent that requires grad (produced by a trainable encoder outside the library): the render backward returns
+        # Encoder training (the reference's default: train/train.py without --freeze_enc): the trunk runs as a torch graph and
+        # its output enters like a supplied latent; the render backward returns d loss / d latent to that graph
+        if (latent is None and not self.encoder.use_custom_resnet and torch.is_grad_enabled() and self.training
+                and not self.stop_encoder_grad and any(p.requires_grad for p in self.encoder.parameters())):
+            latent = self.encoder.forward_torch(images.to(dev, torch.float32))
+        # a latent that requires grad (this trunk's, or a trainable encoder outside the library): the render backward returns
         # d loss / d latent for it (render._RenderFunction, pny_scene_bind_latent_grad)
         self._latent_src = latent if (torch.is_tensor(latent) and latent.requires_grad) else None
         if latent is not None:
             latent = latent.detach().to(dev, torch.float32).contiguous()
             assert latent.dim() == 4 and latent.shape[0] == SB * NS, "latent must be (SB*NS, L, Hl, Wl)"
         else:
+            if getattr(self, "_enc_stale", False):   # the trunk's weights were trained since their last upload
+                self._synced_key = None
+                self._sync()
             images = images.detach().to(dev, torch.float32).contiguous()
         scenes = [self._scene(sb) for sb in range(SB)]
         streams = self.fork_streams(SB)       # the scenes' trunks are independent: one side stream each

@@ -568,6 +568,76 @@ def test_latent_gradient_yolo_render_and_query():
     compare_param_grads(net, sc, which=("mlp_coarse",))
 
 
+def test_encoder_training_gradients_vs_oracle_autograd():
+    """The reference's default training graph (train/train.py without --freeze_enc): images -> ResNet-34 trunk -> latent ->
+    renderer -> loss.  With an unfrozen encoder encode() runs the trunk as a torch graph (SpatialEncoder.forward_torch),
+    the HIP renderer's backward returns d loss / d latent to it, and autograd carries on into the convolutions.  Batch norm
+    in eval mode on both sides (as with the reference's pretrained statistics); trunk parameter gradients against
+    torch.autograd through the oracle's trunk + renderer, MLP gradients from the same backward."""
+    ns, H, W, kc, kf, kfd, n = 2, 64, 64, 16, 8, 4, 32
+    net = make_model(pconf.default_mv()["model"], stop_encoder_grad=False)
+    sd_c, sd_f = synth.mlp_state(801), synth.mlp_state(802)
+    enc = synth.resnet34_state(803, residual_gain=0.25)
+    net.mlp_coarse.load_state_dict({k: torch.from_numpy(v) for k, v in sd_c.items()})
+    net.mlp_fine.load_state_dict({k: torch.from_numpy(v) for k, v in sd_f.items()})
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in enc.items()}, strict=False)
+    net = net.to(DEV).train()
+    net.encoder.eval()
+    assert any(p.requires_grad for p in net.encoder.parameters())
+    poses, tgt = synth.scene_cameras(ns)
+    focal, cc = torch.tensor(0.9 * W), torch.tensor([[W * 0.5, H * 0.5]])
+    images = torch.from_numpy(synth.images(804, ns, H, W))
+    net.encode(images[None], torch.from_numpy(poses)[None], focal, c=cc)
+    assert net.differentiable_latent() is not None
+    # oracle side: the same trunk with leaves that require grad
+    enc_t = {k: torch.from_numpy(v).requires_grad_(torch.from_numpy(v).is_floating_point() and "running" not in k)
+             for k, v in enc.items() if "num_batches" not in k}
+    lat_ref = orc.spatial_encoder(enc_t, images)[0]
+    assert maxabs(net.differentiable_latent(), lat_ref.detach()) < 2e-4
+    mc = {k: torch.from_numpy(v).requires_grad_() for k, v in sd_c.items()}
+    mf = {k: torch.from_numpy(v).requires_grad_() for k, v in sd_f.items()}
+    sc = orc.Scene(mc, mf, lat_ref.detach().numpy(), poses, focal, cc, W, H)
+    sc.mlp_coarse, sc.mlp_fine, sc.latent = mc, mf, lat_ref
+    rs = np.random.RandomState(13)
+    nc = H * W
+    rays = orc.gen_rays(tgt[None], W, H, 0.9 * W, 0.3, 1.8)[0].reshape(-1, 8)
+    sub = rs.choice(nc, 400, replace=False)
+    rays = rays[torch.from_numpy(sub)]
+    dr = dict(u_coarse=rs.rand(400, kc).astype(np.float32), u_fine=rs.rand(400, kf - kfd).astype(np.float32),
+              u_fine2=rs.rand(400, kf - kfd).astype(np.float32), g_depth=rs.randn(400, kfd).astype(np.float32))
+    keep = clean_rays(sc, rays, kc, kf, kfd, dr, n)
+    rays, dr = rays[torch.from_numpy(keep)], {k: v[keep] for k, v in dr.items()}
+    gt = torch.from_numpy(rs.uniform(0, 1, size=(n, 3)).astype(np.float32))
+    ren = NeRFRenderer(n_coarse=kc, n_fine=kf, n_fine_depth=kfd, white_bkgd=True).train()
+    ren.draws = dr
+    out = ren(net, rays[None].to(DEV), want_weights=True)
+    hip = {p: {k: v[0] for k, v in out[p].items()} for p in ("coarse", "fine")}
+    render_loss(hip, gt.to(DEV), True).backward()
+    ref = orc.render(sc, rays, kc, kf, kfd, dr["u_coarse"], dr["u_fine"], dr["u_fine2"], dr["g_depth"])
+    render_loss(ref, gt, True).backward()
+    compare_param_grads(net, sc)
+    worst, checked = 0.0, 0
+    for k, p in net.encoder.model.named_parameters():
+        if k.startswith("layer4"):
+            assert p.grad is None                      # not part of the 4-level pyramid
+            continue
+        g_ref = enc_t["encoder.model." + k].grad
+        assert p.grad is not None and g_ref is not None, k
+        worst = max(worst, grad_check("encoder.model." + k, p.grad, g_ref))     # observed 2.8e-6 of the tensor's max
+        checked += 1
+    assert checked >= 80
+    print("encoder gradients: %d tensors, worst relative error %.2e" % (checked, worst))
+    # an optimizer step on everything, then an eval-mode encode through the NATIVE trunk picks the new weights up
+    opt = torch.optim.SGD(net.parameters(), lr=1e-3)
+    opt.step()
+    net.eval()
+    with torch.no_grad():
+        net.encode(images[None], torch.from_numpy(poses)[None], focal, c=cc)
+        lat_native = net.latent(0)
+        lat_torch = net.encoder.forward_torch(images.to(DEV))
+    assert maxabs(lat_native, lat_torch) < 2e-4 * max(1.0, float(lat_torch.abs().max()))
+
+
 def _batch_for(net_seed, n, kc=16, kf=8, kfd=4, H=32, W=32, ns=2):
     net, sc = scene_pair(ns, H, W, 512, 4, 5, 3, net_seed)
     _, tgt = synth.scene_cameras(ns)
