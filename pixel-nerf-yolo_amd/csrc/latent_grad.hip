@@ -8,8 +8,8 @@
 // (mlp_bwd.hip) has left dh_in(b) there in [feature/4][sample] float4 tiles, which IS the LDS B-operand layout of
 // pixel_linear_kernel (encoder.hip), so staging is a plain copy -- with K = n_view_blocks x 512 and the stacked transposed
 // weights [lin_z[0]^T | lin_z[1]^T | ...] as the packed A operand (api.hip pack_mlp, kept current by pny_model_refresh);
-// the epilogue scatters each accumulator quad (4 consecutive latent channels of one sample) into the sample's four taps
-// with float atomics.  The sum order over samples is therefore not fixed: latent gradients are reproducible to fp32
+// the epilogue turns the accumulators through LDS and scatters 64 consecutive latent channels of one sample per atomic
+// instruction into the sample's four taps (float atomics).  The sum order over samples is therefore not fixed: latent gradients are reproducible to fp32
 // rounding, not bit for bit (the MLP parameter gradients stay deterministic).
 // A workgroup (4 waves) owns 64 samples x 256 latent channels, a wave 64 x 64 (2 x 2 tiles of 32 x 32).
 #include "mlp_core.h"
@@ -21,6 +21,7 @@ constexpr int LG_KC = 32, LG_NW = 4;
 __global__ __launch_bounds__(64 * LG_NW) void latent_grad_kernel(const MlpArgs a, const float* __restrict__ dy_stash, const StashLayout lay,
                                                                  const float* __restrict__ w_cat, float* __restrict__ grad, int nvb) {
     __shared__ float4 bt[2][LG_KC / 4][64 + 1];
+    __shared__ __attribute__((aligned(16))) float tr[LG_NW][32][68];   // epilogue: [wave][sample of the half][channel], 16-byte aligned rows
     __shared__ int tap_off[64][4];
     __shared__ float tap_w[64][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -98,24 +99,32 @@ __global__ __launch_bounds__(64 * LG_NW) void latent_grad_kernel(const MlpArgs a
             __syncthreads();
         }
     }
-    // scatter: accumulator quad (nt, q) of lane (m0, hh), tile mt = latent channels 32 (nt0 + nt) + 8 q + 4 hh + 0..3 of sample 32 mt + m0
-    float* gv = grad + (size_t)v * a.Hl * a.Wl * a.L;
+    // scatter.  In accumulator layout a lane holds 4 channels of ONE sample, i.e. a wave instruction would touch 32 different
+    // pixels' lines; the wave's 64 channels x 32 samples are turned through LDS instead, so that one atomic instruction
+    // adds 64 CONSECUTIVE channels of one sample's tap (two 128-byte lines): 16x fewer line operations at the L2
+    float* gv = grad + (size_t)v * a.Hl * a.Wl * a.L + 32 * nt0 + lane;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-        const int m = 32 * mt + m0;
+        __syncthreads();   // (the staging buffers / the previous half's rows are no longer read)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float wk = tap_w[m][k];
-            if (wk == 0.0f) continue;
-            float* gp = gv + tap_off[m][k];
+        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int q = 0; q < 4; ++q) {
+                float4 t;
+                t.x = acc[nt][mt][4 * q + 0];
+                t.y = acc[nt][mt][4 * q + 1];
+                t.z = acc[nt][mt][4 * q + 2];
+                t.w = acc[nt][mt][4 * q + 3];
+                *reinterpret_cast<float4*>(&tr[wave][m0][32 * nt + 8 * q + 4 * hh]) = t;
+            }
+        __syncthreads();
+        for (int m = 0; m < 32; ++m) {
+            const float val = tr[wave][m][lane];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int n = 32 * (nt0 + nt) + 8 * q + 4 * hh;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) unsafeAtomicAdd(gp + n + r, wk * acc[nt][mt][4 * q + r]);
-                }
+            for (int k = 0; k < 4; ++k) {
+                const float wk = tap_w[32 * mt + m][k];     // wave-uniform
+                if (wk != 0.0f) unsafeAtomicAdd(gv + tap_off[32 * mt + m][k], wk * val);
+            }
         }
     }
 }
