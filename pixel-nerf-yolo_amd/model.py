@@ -477,7 +477,7 @@ class PixelNeRFNet(nn.Module):
         """Unbind and return the gradient in the latent's own layout (SB * NS, L, Hl, Wl), device and dtype."""
         for sb in range(n_scenes):
             check(_lib.load().pny_scene_bind_latent_grad(self._scene(sb), None))
-        return buf.permute(0, 3, 1, 2).to(meta[1], meta[2])
+        return buf.permute(0, 3, 1, 2).contiguous().to(meta[1], meta[2])   # packed NCHW, like the latent it belongs to
 
     def bind_mlp_grads(self):
         """Fresh zeroed gradient buffers for trainable_mlp_parameters(), bound to the native model by name
