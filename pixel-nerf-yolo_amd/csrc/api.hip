@@ -799,6 +799,14 @@ static int run_mlp(pny_scene* s, int mode, const float* xyz, const float* dirs, 
             sp.n_points = n_points;
             m->defer_used[which] += a.n_tiles;
             const int grid = std::min(mlp_max_grid(MLP_8x64), a.n_tiles);
+            // f16x2 variant of the stashing forward (mlp_h2.hip, STASH instantiation): projected latent for the forward, the
+            // raw latent gathered once more per view for lin_z's weight gradient; the same stash layout and contents
+            bool use_h2 = false;
+            if (s->precision != PNY_PRECISION_F32 && mlp_h2_supports(d.n_blocks, d.combine_layer) && s->L % 128 == 0) {
+                if ((rc = ensure_projection(s, fine_w ? 1 : 0, n_points, st, &a.zp, true))) return rc;
+                use_h2 = a.zp != nullptr;
+                if (use_h2) a.tap_stride = a.zp_stride;
+            }
             if (s->timing) {
                 while ((int)s->ev.size() < s->ev_used + 2) {
                     hipEvent_t e;
@@ -807,15 +815,19 @@ static int run_mlp(pny_scene* s, int mode, const float* xyz, const float* dirs, 
                 }
                 PNY_HIP(hipEventRecord(s->ev[s->ev_used], st));
             }
-            launch_mlp_stash(a, grid, st);
+            if (use_h2)
+                launch_mlp_h2_stash(a, grid, st);
+            else
+                launch_mlp_stash(a, grid, st);
             PNY_HIP(hipGetLastError());
             if (s->timing) {
                 PNY_HIP(hipEventRecord(s->ev[s->ev_used + 1], st));
                 s->ev_used += 2;
             }
-            s->last_flops += mlp_flops_per_point(d, s->ns, true) * (double)n_points;
+            s->last_flops += mlp_flops_per_point(d, s->ns, !use_h2) * (double)n_points;
             s->last_flops_ref += mlp_flops_per_point(d, s->ns, true) * (double)n_points;
-            s->last_projected = false;
+            s->last_projected = use_h2;
+            s->last_f16x2 = use_h2;
             s->last_launches += 1;
             return 0;
         }

@@ -236,9 +236,24 @@ __device__ __forceinline__ void split4(float a, float b, float c, float d, h4& p
 // Block entry / GEMM epilogue: acc += bias (+ the staged fp32 projection, ADDZ), then the planes of relu(acc) go to the
 // slots of the lane's own feature quads -- the bytes the staged projection was read from, so no other lane's data is touched.
 // `bias`: a 512-float vector of the workgroup's LDS bias table.
-template <bool ADDZ>
-__device__ __forceinline__ void h2epilogue(f32x16 (&acc)[h2::NT][h2::MT], const float* bias, char* planes, int wave, int lane) {
+// Stores into the tile's record of the X stash go through a raw buffer resource with 32-bit offsets (64-bit pointers per
+// accumulator quad cost 32 address registers per epilogue).  The whole offset travels in the VGPR, the scalar offset stays
+// the constant 0: with an SGPR there the compiler assumes that a 128-bit store has read its data registers by the next
+// instruction and lets a VALU instruction overwrite them at once -- measured on gfx950: the first dword of ~20 % of such
+// stores then carried the NEW value (lin_in / lin_z weight gradients off by 1-3 %, in exactly the `.x` columns).  Without a
+// register in soffset LLVM's hazard recogniser inserts the wait state.
+__device__ __forceinline__ void stash_store(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, float a, float b, float c, float d) {
+    const f32x4 v = {a, b, c, d};
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, voff + soff, 0, 0);
+}
+
+// STASH (training forward): relu(acc + ...) is also written in fp32 to `stash` in the [feature/4][sample] float4 tile layout of
+// the backward's operand stash (pny_common.h StashLayout; the same values the fp32 STASH kernel of mlp.hip writes).
+template <bool ADDZ, bool STASH = false>
+__device__ __forceinline__ void h2epilogue(f32x16 (&acc)[h2::NT][h2::MT], const float* bias, char* planes, int wave, int lane,
+                                           __amdgpu_buffer_rsrc_t stash = __amdgpu_buffer_rsrc_t(), unsigned stash_off = 0) {
     using namespace h2;
+    const unsigned stash_lane = (unsigned)(((8 * NT * wave + (lane >> 5)) * TM + (lane & 31)) * 16);
     const int m0 = lane & 31, hh = lane >> 5;
     const float* bl = bias + 32 * NT * wave + 4 * hh;
     // accumulator quad (nt, q) of this lane = features 32 NT wave + 32 nt + 8 q + 4 hh + 0..3: row 4 NT wave + 4 nt + q, half hh
@@ -278,8 +293,10 @@ __device__ __forceinline__ void h2epilogue(f32x16 (&acc)[h2::NT][h2::MT], const 
                 acc[nt][mt][4 * q + 1] = x1;
                 acc[nt][mt][4 * q + 2] = x2;
                 acc[nt][mt][4 * q + 3] = x3;
+                const float r0 = relu1(x0), r1 = relu1(x1), r2 = relu1(x2), r3 = relu1(x3);
+                if constexpr (STASH) stash_store(stash, stash_lane, stash_off + (unsigned)(((8 * nt + 2 * q) * TM + 32 * mt) * 16), r0, r1, r2, r3);
                 h4 p0, p1;
-                split4(relu1(x0), relu1(x1), relu1(x2), relu1(x3), p0, p1);
+                split4(r0, r1, r2, r3, p0, p1);
                 *reinterpret_cast<h4*>(s0) = p0;
                 *reinterpret_cast<h4*>(s1) = p1;
             }
@@ -322,7 +339,9 @@ __device__ __forceinline__ void h2gather_commit(const GatherTaps<h2::C, 2>& g, c
 
 // per (view, tile) prologue: the lin_in B operand (positional code, view dirs) as f16 planes in rows 0..7 of each plane, and
 // the tap table; the arithmetic of prologue<C>() in mlp_core.h
-__device__ __forceinline__ void h2prologue(const MlpArgs& a, int v, long long tile, char* planes, float4* tap_tab, int tid) {
+template <bool STASH>
+__device__ __forceinline__ void h2prologue(const MlpArgs& a, int v, long long tile, char* planes, float4* tap_tab, int tid,
+                                           __amdgpu_buffer_rsrc_t stash = __amdgpu_buffer_rsrc_t(), unsigned stash_xin = 0, float4* tap_raw = nullptr) {
     using namespace h2;
     constexpr int NPART = THREADS / TM;
     const int m = tid % TM, part = tid / TM;
@@ -340,8 +359,10 @@ __device__ __forceinline__ void h2prologue(const MlpArgs& a, int v, long long ti
     }
     for (int g = part; g < D_IN_PAD / 4; g += NPART) {
         h4 p0, p1;
-        split4(input_entry(4 * g + 0, xr, vd, a.freq_factor, a.num_freqs), input_entry(4 * g + 1, xr, vd, a.freq_factor, a.num_freqs),
-               input_entry(4 * g + 2, xr, vd, a.freq_factor, a.num_freqs), input_entry(4 * g + 3, xr, vd, a.freq_factor, a.num_freqs), p0, p1);
+        const float e0 = input_entry(4 * g + 0, xr, vd, a.freq_factor, a.num_freqs), e1 = input_entry(4 * g + 1, xr, vd, a.freq_factor, a.num_freqs);
+        const float e2 = input_entry(4 * g + 2, xr, vd, a.freq_factor, a.num_freqs), e3 = input_entry(4 * g + 3, xr, vd, a.freq_factor, a.num_freqs);
+        split4(e0, e1, e2, e3, p0, p1);
+        if constexpr (STASH) stash_store(stash, (unsigned)((g * TM + m) * 16), stash_xin, e0, e1, e2, e3);   // lin_in's B operand, [feature/4][sample]
         char* s0 = planes + (g >> 1) * (2 * ROW_BYTES) + m * 16 + 8 * (g & 1);
         *reinterpret_cast<h4*>(s0) = p0;
         *reinterpret_cast<h4*>(s0 + ROW_BYTES) = p1;
@@ -366,28 +387,40 @@ __device__ __forceinline__ void h2prologue(const MlpArgs& a, int v, long long ti
         const float xs[4] = {x0, x1, x0, x1};
         const float ys[4] = {y0, y0, y1, y1};
         const bool cull = a.yolo && !(xc[2] < 0.0f);
-        int offs[4];
+        int offs[4], raw[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const bool ok = (xs[k] >= 0.f) && (xs[k] <= (float)(a.Wl - 1)) && (ys[k] >= 0.f) && (ys[k] <= (float)(a.Hl - 1));
-            offs[k] = 0;
-            if (ok)
+            offs[k] = raw[k] = 0;
+            if (ok) {
                 offs[k] = ((int)ys[k] * a.Wl + (int)xs[k]) * a.tap_stride;
-            else
+                raw[k] = ((int)ys[k] * a.Wl + (int)xs[k]) * a.L;
+            } else {
                 wgt[k] = wgt[k] * 0.0f;
+            }
             if (cull || (a.yolo && (wgt[k] != wgt[k]))) wgt[k] = 0.0f;
         }
         tap_tab[2 * m] = make_float4(__int_as_float(offs[0]), __int_as_float(offs[1]), __int_as_float(offs[2]), __int_as_float(offs[3]));
         tap_tab[2 * m + 1] = make_float4(wgt[0], wgt[1], wgt[2], wgt[3]);
+        if constexpr (STASH) {   // the same taps addressing the latent itself (pixel x L)
+            tap_raw[2 * m] = make_float4(__int_as_float(raw[0]), __int_as_float(raw[1]), __int_as_float(raw[2]), __int_as_float(raw[3]));
+            tap_raw[2 * m + 1] = make_float4(wgt[0], wgt[1], wgt[2], wgt[3]);
+        }
     }
 }
 
+// STASH = the training forward (pny_scene_stash_next_render): the same kernel also writes every operand the backward needs to
+// the tile's record of the X stash in fp32 -- the positional-code inputs, the interpolated latent z (an extra gather of the
+// raw latent per view: the weight gradient of lin_z needs it, the forward itself only the projected maps), relu(h_in) and
+// relu(net) of every block, relu(h_top) -- in the layout the fp32 STASH kernel of mlp.hip writes.
+template <bool STASH>
 __global__ __launch_bounds__(h2::THREADS, 2) void pny_mlp_h2_kernel(const MlpArgs a) {
     using namespace h2;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     char* planes = smem_raw;
     float4* tap_tab = reinterpret_cast<float4*>(smem_raw + ACT_BYTES);
     float* bias_tab = reinterpret_cast<float*>(smem_raw + ACT_BYTES + TAP_BYTES);   // [b_in, b_fc0[0], b_fc1[0], b_fc0[1], ...][512]
+    float4* tap_raw = reinterpret_cast<float4*>(smem_raw + lds_bytes(a.n_blocks));   // STASH only: taps addressing the raw latent
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* slab = a.scratch + (size_t)blockIdx.x * (TM * HID) + (size_t)wave * (NT * MT * 16 * 64) + 4 * lane;
     const int nb = a.n_blocks;
@@ -432,7 +465,11 @@ __global__ __launch_bounds__(h2::THREADS, 2) void pny_mlp_h2_kernel(const MlpArg
         // one residual block from "planes hold relu(h_in)" on: net = fc_0(.), h += fc_1(relu(net + b_fc0)).  `next_c0` >= 0:
         // the first chunk of the NEXT block's projection (channel offset next_c0) is fetched into gather buffer 0
         // underneath the fc_1 GEMM -- `net` is dead there, its registers hold the chunk.
-        auto block_tail = [&](int blk, const H2Seg& after, const float* slab_in, int next_c0) {
+        // this tile's record of the X stash as a buffer resource; offsets below are bytes inside the record
+        __amdgpu_buffer_rsrc_t xr = __amdgpu_buffer_rsrc_t();
+        if constexpr (STASH)
+            xr = __builtin_amdgcn_make_buffer_rsrc(a.stash_x + tile * a.lay.x_tile, 0, (int)(a.lay.x_tile * 4), 0x00020000);
+        auto block_tail = [&](int blk, const H2Seg& after, const float* slab_in, int next_c0, unsigned stash_net) {
             HS_T0();
             h2zero<NT, MT>(net);
             __syncthreads();
@@ -441,7 +478,7 @@ __global__ __launch_bounds__(h2::THREADS, 2) void pny_mlp_h2_kernel(const MlpArg
             HS_LAP(HS_GEMM);
             __syncthreads();
             HS_LAP(HS_EPI_WAIT);
-            h2epilogue<false>(net, fc0_bias(blk), planes, wave, lane);
+            h2epilogue<false, STASH>(net, fc0_bias(blk), planes, wave, lane, xr, stash_net);
             // three exclusive continuations (the running sum of the other views and the prefetched chunk both want the
             // registers of `net`: written as one if / else chain so that the allocator never has to provide for both)
             if (slab_in) {
@@ -473,11 +510,42 @@ __global__ __launch_bounds__(h2::THREADS, 2) void pny_mlp_h2_kernel(const MlpArg
         };
         for (int v = 0; v < a.NS; ++v) {
             const H2Seg after_view = v + 1 < a.NS ? s_in : (nvb < nb ? fc0seg(nvb) : s_in);
+            const unsigned x_view = STASH ? (unsigned)v * (unsigned)a.lay.x_view * 4u : 0u;
+            auto act_slot = [&](int i) { return x_view + ((unsigned)a.lay.x_act + (unsigned)i * (unsigned)STASH_SLOT) * 4u; };
             HS_T0();
             __syncthreads();
-            h2prologue(a, v, tile, planes, tap_tab, tid);
+            h2prologue<STASH>(a, v, tile, planes, tap_tab, tid, xr, x_view + (unsigned)a.lay.x_in * 4u, tap_raw);
             h2zero<NT, MT>(h);
             __syncthreads();
+            if constexpr (STASH) {
+                // z = the interpolated latent of this view (reference encoder.py:101), the B operand of lin_z's weight
+                // gradient: gathered from the latent itself, 128 channels at a time, two chunks in flight, written straight
+                // to the stash (a lane holds 4 channels of one sample = one float4 of the [channel/4][sample] tile)
+                const unsigned xz = x_view + (unsigned)a.lay.x_z * 4u;
+                gather_setup<C>(g, a.latent + (size_t)v * a.Hl * a.Wl * a.L, tap_raw, wave, lane);
+                const int nch = a.L / GCH;
+                const unsigned zlane = (unsigned)(((lane >> 3) * TM + (wave % 8) * 8 + (lane & 7)) * 16);
+                auto put = [&](const float4(&x)[4][4], int c) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float4 r;
+                        r.x = __builtin_fmaf(x[i][3].x, g.w[3], __builtin_fmaf(x[i][2].x, g.w[2], __builtin_fmaf(x[i][1].x, g.w[1], x[i][0].x * g.w[0])));
+                        r.y = __builtin_fmaf(x[i][3].y, g.w[3], __builtin_fmaf(x[i][2].y, g.w[2], __builtin_fmaf(x[i][1].y, g.w[1], x[i][0].y * g.w[0])));
+                        r.z = __builtin_fmaf(x[i][3].z, g.w[3], __builtin_fmaf(x[i][2].z, g.w[2], __builtin_fmaf(x[i][1].z, g.w[1], x[i][0].z * g.w[0])));
+                        r.w = __builtin_fmaf(x[i][3].w, g.w[3], __builtin_fmaf(x[i][2].w, g.w[2], __builtin_fmaf(x[i][1].w, g.w[1], x[i][0].w * g.w[0])));
+                        stash_store(xr, zlane, xz + (unsigned)((32 * c + 8 * i) * TM * 16), r.x, r.y, r.z, r.w);
+                    }
+                };
+                gather_issue<C, 0>(g, 0, wave);
+                for (int c = 0; c < nch; c += 2) {
+                    if (c + 1 < nch) gather_issue<C, 1>(g, (c + 1) * GCH, wave);
+                    __builtin_amdgcn_sched_barrier(0);
+                    put(g.x[0], c);
+                    if (c + 2 < nch) gather_issue<C, 0>(g, (c + 2) * GCH, wave);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (c + 1 < nch) put(g.x[1], c + 1);
+                }
+            }
             gather_setup<C>(g, a.zp + (size_t)v * a.Hl * a.Wl * a.zp_stride, tap_tab, wave, lane);
             gather_issue<C, 0>(g, 0, wave);   // block 0, chunk 0
             HS_LAP(HS_PROLOGUE);
@@ -506,9 +574,9 @@ __global__ __launch_bounds__(h2::THREADS, 2) void pny_mlp_h2_kernel(const MlpArg
                 HS_LAP(HS_GATHER);
                 __syncthreads();  // projection visible
                 HS_LAP(HS_GATHER_WAIT);
-                h2epilogue<true>(h, entry_bias(blk), planes, wave, lane);
+                h2epilogue<true, STASH>(h, entry_bias(blk), planes, wave, lane, xr, act_slot(2 * blk));
                 HS_LAP(HS_EPI);
-                block_tail(blk, after, slab_in, next_c0);
+                block_tail(blk, after, slab_in, next_c0, act_slot(2 * blk + 1));
             };
 #ifdef PNY_H2_NOPREFETCH
             for (int blk = 0; blk + 1 < nvb; ++blk) {
@@ -535,18 +603,19 @@ __global__ __launch_bounds__(h2::THREADS, 2) void pny_mlp_h2_kernel(const MlpArg
                 HS_LAP(HS_SLAB);
             }
         }
+        auto post_slot = [&](int i) { return ((unsigned)a.lay.x_post + (unsigned)i * (unsigned)STASH_SLOT) * 4u; };
         for (int blk = nvb; blk < nb; ++blk) {
             HS_T0();
             __syncthreads();
             HS_LAP(HS_EPI_WAIT);
-            h2epilogue<false>(h, entry_bias(blk), planes, wave, lane);
+            h2epilogue<false, STASH>(h, entry_bias(blk), planes, wave, lane, xr, post_slot(2 * (blk - nvb)));
             HS_LAP(HS_EPI);
-            block_tail(blk, blk + 1 < nb ? fc0seg(blk + 1) : s_in, nullptr, -1);
+            block_tail(blk, blk + 1 < nb ? fc0seg(blk + 1) : s_in, nullptr, -1, post_slot(2 * (blk - nvb) + 1));
         }
         // out = lin_out(relu(h + b_fc1[last])) (reference resnetfc.py:185) + output head (models.py:312-317)
         HS_T0();
         __syncthreads();
-        h2epilogue<false>(h, entry_bias(nb), planes, wave, lane);
+        h2epilogue<false, STASH>(h, entry_bias(nb), planes, wave, lane, xr, post_slot(2 * (nb - nvb)));
         __syncthreads();
         for (int idx = tid; idx < a.d_out * TM; idx += THREADS) {
             const int o = idx / TM, m = idx % TM;
@@ -587,14 +656,16 @@ __global__ __launch_bounds__(h2::THREADS, 2) void pny_mlp_h2_kernel(const MlpArg
 
 bool mlp_h2_supports(int n_blocks, int combine_layer) { return n_blocks <= h2::MAX_NB && combine_layer >= 1; }
 
-void launch_mlp_h2(const MlpArgs& a, int grid, hipStream_t st) {
+template <bool STASH>
+static void launch_mlp_h2_t(const MlpArgs& a, int grid, hipStream_t st) {
     static bool attr_set[64] = {};
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
     dev_ &= 63;
+    const int extra = STASH ? h2::TAP_BYTES : 0;   // second tap table
     if (!attr_set[dev_]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pny_mlp_h2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  h2::lds_bytes(h2::MAX_NB));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pny_mlp_h2_kernel<STASH>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  h2::lds_bytes(h2::MAX_NB) + extra);
         attr_set[dev_] = true;
     }
 #ifdef PNY_H2_STAMP
@@ -606,7 +677,7 @@ void launch_mlp_h2(const MlpArgs& a, int grid, hipStream_t st) {
     }
     (void)hipMemsetAsync(dbuf, 0, nst * sizeof(unsigned long long), st);
 #endif
-    hipLaunchKernelGGL(pny_mlp_h2_kernel, dim3(grid), dim3(h2::THREADS), h2::lds_bytes(a.n_blocks), st, a);
+    hipLaunchKernelGGL(pny_mlp_h2_kernel<STASH>, dim3(grid), dim3(h2::THREADS), h2::lds_bytes(a.n_blocks) + extra, st, a);
 #ifdef PNY_H2_STAMP
     {
         std::vector<unsigned long long> hst(nst);
@@ -615,11 +686,15 @@ void launch_mlp_h2(const MlpArgs& a, int grid, hipStream_t st) {
         double sum[HS_N] = {0};
         for (size_t i = 0; i < nst; ++i) sum[i % HS_N] += (double)hst[i];
         static const char* names[HS_N] = {"total", "gemm", "gather-barrier-wait", "gather", "epilogue-barrier-wait", "epilogue", "prologue", "lin_out", "slab"};
-        fprintf(stderr, "[h2 stamp] tiles=%d grid=%d:", a.n_tiles, grid);
+        fprintf(stderr, "[h2 stamp%s] tiles=%d grid=%d:", STASH ? ", stash" : "", a.n_tiles, grid);
         for (int i = 0; i < HS_N; ++i) fprintf(stderr, " %s=%.1f%%", names[i], 100.0 * sum[i] / sum[0]);
         fprintf(stderr, " (mean wave cycles %.4g)\n", sum[0] / ((double)grid * 8));
     }
 #endif
 }
+
+void launch_mlp_h2(const MlpArgs& a, int grid, hipStream_t st) { launch_mlp_h2_t<false>(a, grid, st); }
+// training forward: a.stash_x / a.lay set, a.zp AND a.latent valid (152 + 2 KiB of LDS for 5 blocks)
+void launch_mlp_h2_stash(const MlpArgs& a, int grid, hipStream_t st) { launch_mlp_h2_t<true>(a, grid, st); }
 
 }  // namespace pny

@@ -187,7 +187,8 @@ void launch_mlp_stash(const MlpArgs& a, int grid, hipStream_t st);  // 8x64 shap
 void launch_latent_grad(const MlpArgs& a, const float* dy_stash, const StashLayout& lay, const float* w_cat, float* grad, int nvb,
                         hipStream_t st);
 bool mlp_h2_supports(int n_blocks, int combine_layer);
-void launch_mlp_h2(const MlpArgs& a, int grid, hipStream_t st);     // 8x64 shape, projected latent, split-f16 operands (mlp_h2.hip)
+void launch_mlp_h2(const MlpArgs& a, int grid, hipStream_t st);
+void launch_mlp_h2_stash(const MlpArgs& a, int grid, hipStream_t st);   // + the backward's operand stash (a.stash_x, a.lay)     // 8x64 shape, projected latent, split-f16 operands (mlp_h2.hip)
 int mlp_max_grid(int variant);      // resident workgroups = persistent grid size
 int mlp_tile_samples(int variant);  // samples per workgroup tile (32 or 64)
 size_t mlp_scratch_floats();

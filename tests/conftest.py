@@ -16,6 +16,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "f16x2_forward: backward test that keeps the default (f16x2) training forward")
 
 
 @pytest.fixture(scope="session")

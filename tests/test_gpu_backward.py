@@ -22,6 +22,18 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-4
 
 
+@pytest.fixture(autouse=True)
+def training_forward_arithmetic(request, monkeypatch):
+    """Which kernel writes the backward's operand stash in the training forward (scene default read at pny_scene_create):
+    the comparisons with torch.autograd through the oracle pin the fp32 kernel in the reference's operation order, whose
+    pre-activations agree with the oracle's to ~1e-6, so that both sides mask the same relu units on the selected points
+    (AMBIG below).  The default -- the f16x2 kernel on the projected latent -- evaluates the same function in another order:
+    its gradients are those of a forward that masks a few near-zero units differently, which moves a tensor by ~1 / n_samples
+    of its scale per unit.  Tests marked `f16x2_forward` check that path against the fp32 path instead."""
+    if "f16x2_forward" not in request.keywords:
+        monkeypatch.setenv("PNYOLO_MLP_PRECISION", "f32")
+
+
 def grad_check(name, got, ref, rtol=RTOL):
     ref = torch.as_tensor(np.asarray(ref), dtype=torch.float32)
     scale = max(float(ref.abs().max()), 1e-20)
@@ -636,6 +648,47 @@ def test_encoder_training_gradients_vs_oracle_autograd():
         lat_native = net.latent(0)
         lat_torch = net.encoder.forward_torch(images.to(DEV))
     assert maxabs(lat_native, lat_torch) < 2e-4 * max(1.0, float(lat_torch.abs().max()))
+
+
+@pytest.mark.f16x2_forward
+def test_f16x2_training_forward_against_fp32_training_forward(monkeypatch):
+    """The default training forward (f16x2 kernel, STASH instantiation of mlp_h2.hip: projected latent, the backward's
+    operands written from its epilogues) against the fp32 reference-order forward on the same super-batch: rendered values
+    within 1e-4, and every parameter gradient within 0.5 % of the tensor's norm (observed: 6e-5 for the block weights, 6e-4 for
+    lin_z, whose sum over samples cancels most) -- unfiltered rays, so the two forwards may mask a few near-zero relu units
+    differently (see the fixture above).  This test found the 128-bit-store hazard recorded at mlp_h2.hip stash_store: 1-3 %
+    errors confined to the `.x` columns of lin_in / lin_z."""
+    SB, ns, H, W, kc, kf, kfd, n = 2, 3, 64, 64, 32, 16, 8, 256
+    rs = np.random.RandomState(31)
+    grads, outs, used = {}, {}, {}
+    for prec in ("f32", "f16x2"):
+        monkeypatch.setenv("PNYOLO_MLP_PRECISION", prec)
+        net = make_model(pconf.default_mv()["model"], stop_encoder_grad=True)
+        net.mlp_coarse.load_state_dict({k: torch.from_numpy(v) for k, v in synth.mlp_state(901).items()})
+        net.mlp_fine.load_state_dict({k: torch.from_numpy(v) for k, v in synth.mlp_state(902).items()})
+        net = net.to(DEV).train()
+        poses = np.stack([synth.scene_cameras(ns, radius=1.3 + 0.05 * i)[0] for i in range(SB)])
+        lat = torch.from_numpy(np.concatenate([synth.latent(903 + i, ns, 512, H // 2, W // 2) for i in range(SB)]))
+        net.encode(torch.zeros(SB, ns, 3, H, W), torch.from_numpy(poses), torch.tensor(0.9 * W), latent=lat)
+        _, tgt = synth.scene_cameras(ns)
+        rays_all = orc.gen_rays(tgt[None], W, H, 0.9 * W, 0.8, 1.8)[0].reshape(-1, 8)
+        r0 = np.random.RandomState(32)
+        rays = torch.stack([rays_all[torch.from_numpy(r0.choice(H * W, n, replace=False))] for _ in range(SB)]).to(DEV)
+        gt = torch.from_numpy(r0.uniform(0, 1, size=(SB, n, 3)).astype(np.float32)).to(DEV)
+        ren = NeRFRenderer(n_coarse=kc, n_fine=kf, n_fine_depth=kfd, white_bkgd=True).train()
+        ren.draws = dict(u_coarse=r0.rand(SB * n, kc).astype(np.float32), u_fine=r0.rand(SB * n, kf - kfd).astype(np.float32),
+                         u_fine2=r0.rand(SB * n, kf - kfd).astype(np.float32), g_depth=r0.randn(SB * n, kfd).astype(np.float32))
+        out = ren(net, rays, want_weights=True)
+        used[prec] = net.last_launch_f16x2()
+        render_loss(out, gt, True).backward()
+        outs[prec] = out["coarse"]["rgb"].detach().clone()     # (the fine pass may flip an importance-sampling bin)
+        grads[prec] = {k: p.grad.detach().clone() for k, p in list(net.mlp_coarse.named_parameters()) + [("f." + k_, p_) for k_, p_ in net.mlp_fine.named_parameters()]}
+    assert used == {"f32": False, "f16x2": True}
+    assert maxabs(outs["f16x2"], outs["f32"]) < 1e-4
+    rels = {k: float((grads["f16x2"][k] - g32).norm() / g32.norm().clamp_min(1e-30)) for k, g32 in grads["f32"].items()}
+    print("f16x2 vs fp32 training forward, relative L2 difference per gradient tensor:",
+          " ".join("%s=%.1e" % kv for kv in sorted(rels.items(), key=lambda kv: -kv[1])[:12]))
+    assert max(rels.values()) < 5e-3, max(rels.items(), key=lambda kv: kv[1])
 
 
 def _batch_for(net_seed, n, kc=16, kf=8, kfd=4, H=32, W=32, ns=2):
