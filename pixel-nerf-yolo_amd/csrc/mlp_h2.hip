@@ -238,10 +238,11 @@ __device__ __forceinline__ void split4(float a, float b, float c, float d, h4& p
 // `bias`: a 512-float vector of the workgroup's LDS bias table.
 // Stores into the tile's record of the X stash go through a raw buffer resource with 32-bit offsets (64-bit pointers per
 // accumulator quad cost 32 address registers per epilogue).  The whole offset travels in the VGPR, the scalar offset stays
-// the constant 0: with an SGPR there the compiler assumes that a 128-bit store has read its data registers by the next
-// instruction and lets a VALU instruction overwrite them at once -- measured on gfx950: the first dword of ~20 % of such
-// stores then carried the NEW value (lin_in / lin_z weight gradients off by 1-3 %, in exactly the `.x` columns).  Without a
-// register in soffset LLVM's hazard recogniser inserts the wait state.
+// the constant 0.  With the slot offset in an SGPR soffset the compiler placed VALU writes of the store's first data register
+// directly behind the store (it treats that form as hazard-free) and inside this kernel the first dword of ~20 % of those
+// stores carried the NEW value (lin_in / lin_z weight gradients off by 1-3 %, in exactly the `.x` columns); with the constant
+// form LLVM's hazard recogniser inserts the wait state and the stash is exact.  In isolation only the constant form shows the
+// hazard (tools/ubench/lds_write_data_hazard.hip), so what else contributed here is open; this form is the safe one.
 __device__ __forceinline__ void stash_store(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, float a, float b, float c, float d) {
     const f32x4 v = {a, b, c, d};
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, voff + soff, 0, 0);
