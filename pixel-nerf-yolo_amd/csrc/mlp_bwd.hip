@@ -49,12 +49,41 @@ __device__ __forceinline__ void acc_zero(f32x16 (&t)[NT][MT]) {
             for (int r = 0; r < 16; ++r) t[nt][mt][r] = 0.f;
 }
 
+// The two stashes of a tile are addressed through raw buffer resources (one per tile record, 32-bit byte offsets): a slot
+// access in accumulator layout is the lane's own offset (one VGPR for the whole kernel) + the slot's offset + a
+// compile-time constant per accumulator quad.  With 64-bit pointers every quad had its own address pair, and those spilled
+// inside the GEMM loops.  Stores keep the whole offset in the VGPR operand and the constant 0 in soffset (see mlp_h2.hip
+// stash_store: the form for which the compiler inserts the >64-bit store-data wait state).
+struct StashRef {
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned off;   // byte offset of the slot inside the record
+};
+__device__ __forceinline__ float4 stash_ld(const StashRef& r, unsigned lane_off, unsigned c) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r.rsrc, lane_off, r.off + c, 0);
+    const f32x4 f = __builtin_bit_cast(f32x4, v);
+    return make_float4(f.x, f.y, f.z, f.w);
+}
+__device__ __forceinline__ void stash_st(const StashRef& r, unsigned lane_off, unsigned c, const float4& v) {
+    const f32x4 f = {v.x, v.y, v.z, v.w};
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f), r.rsrc, lane_off + r.off + c, 0, 0);
+}
+// byte offset of accumulator quad (nt, mt, q) relative to the lane's own offset acc_lane_off()
+template <int NT, int MT>
+__device__ __forceinline__ constexpr unsigned quad_off(int nt, int mt, int q) {
+    return (unsigned)(((8 * nt + 2 * q) * (32 * MT) + 32 * mt) * 16);
+}
+template <int NT, int MT>
+__device__ __forceinline__ unsigned acc_lane_off(int wave, int lane) {
+    return (unsigned)(((8 * NT * wave + (lane >> 5)) * (32 * MT) + (lane & 31)) * 16);
+}
+
 // act[feature/4][m] = acc (no activation): the B operand of the next transposed GEMM; optionally also to the dY stash.
 template <int NT, int MT, bool TO_LDS, bool TO_GLOBAL>
-__device__ __forceinline__ void store_plain(const f32x16 (&acc)[NT][MT], float4* __restrict__ act, float4* __restrict__ g,
+__device__ __forceinline__ void store_plain(const f32x16 (&acc)[NT][MT], float4* __restrict__ act, const StashRef& g,
                                             int wave, int lane) {
     constexpr int TMc = 32 * MT;
     const int m0 = lane & 31, hh = lane >> 5;
+    const unsigned lo = acc_lane_off<NT, MT>(wave, lane);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -65,22 +94,21 @@ __device__ __forceinline__ void store_plain(const f32x16 (&acc)[NT][MT], float4*
                                              acc[nt][mt][4 * q + 3]);
                 const int idx = (8 * NT * wave + 8 * nt + 2 * q + hh) * TMc + 32 * mt + m0;
                 if (TO_LDS) act[idx] = v;
-                if (TO_GLOBAL) g[idx] = v;
+                if (TO_GLOBAL) stash_st(g, lo, quad_off<NT, MT>(nt, mt, q), v);
             }
 }
 
 // acc = (x > 0) ? acc : 0 with x = the stashed relu'd activation of the same element (accumulator layout).
 template <int NT, int MT>
-__device__ __forceinline__ void mask_by(f32x16 (&acc)[NT][MT], const float4* __restrict__ x, int wave, int lane) {
-    constexpr int TMc = 32 * MT;
-    const int m0 = lane & 31, hh = lane >> 5;
+__device__ __forceinline__ void mask_by(f32x16 (&acc)[NT][MT], const StashRef& x, int wave, int lane) {
+    const unsigned lo = acc_lane_off<NT, MT>(wave, lane);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             float4 xv[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) xv[q] = x[(8 * NT * wave + 8 * nt + 2 * q + hh) * TMc + 32 * mt + m0];
+            for (int q = 0; q < 4; ++q) xv[q] = stash_ld(x, lo, quad_off<NT, MT>(nt, mt, q));
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 acc[nt][mt][4 * q + 0] = xv[q].x > 0.f ? acc[nt][mt][4 * q + 0] : 0.f;
@@ -92,16 +120,15 @@ __device__ __forceinline__ void mask_by(f32x16 (&acc)[NT][MT], const float4* __r
 }
 
 template <int NT, int MT>
-__device__ __forceinline__ void acc_load(f32x16 (&acc)[NT][MT], const float4* __restrict__ g, int wave, int lane) {
-    constexpr int TMc = 32 * MT;
-    const int m0 = lane & 31, hh = lane >> 5;
+__device__ __forceinline__ void acc_load(f32x16 (&acc)[NT][MT], const StashRef& g, int wave, int lane) {
+    const unsigned lo = acc_lane_off<NT, MT>(wave, lane);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 v = g[(8 * NT * wave + 8 * nt + 2 * q + hh) * TMc + 32 * mt + m0];
+                const float4 v = stash_ld(g, lo, quad_off<NT, MT>(nt, mt, q));
                 acc[nt][mt][4 * q + 0] = v.x;
                 acc[nt][mt][4 * q + 1] = v.y;
                 acc[nt][mt][4 * q + 2] = v.z;
@@ -116,12 +143,12 @@ __device__ __forceinline__ void acc_load(f32x16 (&acc)[NT][MT], const float4* __
 template <class C>
 __device__ __forceinline__ void block_bwd(f32x16 (&dh)[C::NT][C::MT], WRing<C::WDEPTH, C::NT>& ring, const WStream& ws,
                                           const WSeg& s_fc1t, const WSeg& s_fc0t, const WSeg& after, float4* act,
-                                          const float4* x_h, const float4* x_net, float4* dy_dnet, float4* dy_dh,
+                                          const StashRef& x_h, const StashRef& x_net, const StashRef& dy_dnet, const StashRef& dy_dh,
                                           float scale, int wave, int lane) {
     constexpr int NT = C::NT, MT = C::MT;
     f32x16 t[NT][MT];
     __syncthreads();  // every wave is done reading the buffer (previous GEMM)
-    store_plain<NT, MT, true, false>(dh, act, nullptr, wave, lane);
+    store_plain<NT, MT, true, false>(dh, act, dy_dh, wave, lane);
     __syncthreads();
     acc_zero<NT, MT>(t);
     gemm_run<C>(t, ring, ws, s_fc1t, s_fc0t, act, lane);
@@ -160,15 +187,17 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void pny_mlp_bwd_kernel(const B
     const float inv_ns = 1.0f / (float)a.NS;
 
     for (long long tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-        const float* x_rec = a.x_stash + tile * a.lay.x_tile;
         float* dy_rec = a.dy_stash + tile * a.lay.dy_tile;
-        auto x_post = [&](int i) { return reinterpret_cast<const float4*>(x_rec + a.lay.x_post + (size_t)i * STASH_SLOT); };
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x_stash + tile * a.lay.x_tile), 0,
+                                                                            (int)(a.lay.x_tile * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(dy_rec, 0, (int)(a.lay.dy_tile * 4), 0x00020000);
+        auto x_post = [&](int i) { return StashRef{xr, ((unsigned)a.lay.x_post + (unsigned)i * (unsigned)STASH_SLOT) * 4u}; };
         auto x_act = [&](int v, int i) {
-            return reinterpret_cast<const float4*>(x_rec + (size_t)v * a.lay.x_view + a.lay.x_act + (size_t)i * STASH_SLOT);
+            return StashRef{xr, ((unsigned)v * (unsigned)a.lay.x_view + (unsigned)a.lay.x_act + (unsigned)i * (unsigned)STASH_SLOT) * 4u};
         };
         float4* dy_draw = reinterpret_cast<float4*>(dy_rec + a.lay.dy_post);
-        auto dy_post = [&](int i) { return reinterpret_cast<float4*>(dy_rec + a.lay.dy_post + STASH_SMALL + (size_t)i * STASH_SLOT); };
-        auto dy_view = [&](int v, int i) { return reinterpret_cast<float4*>(dy_rec + (size_t)v * a.lay.dy_view + (size_t)i * STASH_SLOT); };
+        auto dy_post = [&](int i) { return StashRef{yr, ((unsigned)a.lay.dy_post + (unsigned)STASH_SMALL + (unsigned)i * (unsigned)STASH_SLOT) * 4u}; };
+        auto dy_view = [&](int v, int i) { return StashRef{yr, ((unsigned)v * (unsigned)a.lay.dy_view + (unsigned)i * (unsigned)STASH_SLOT) * 4u}; };
 
         // ---- head: gradient w.r.t. lin_out's output through sigmoid / relu (reference models.py:312-317), as the B
         // operand of lin_out^T (d_out rows padded to 64) and as the dY of lin_out for the weight-gradient GEMM
@@ -211,7 +240,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void pny_mlp_bwd_kernel(const B
                          dy_post(2 + 2 * i), b == nvb ? inv_ns : 1.0f, wave, lane);
         }
         // dhm: what every view's last per-view block receives (dh_top itself when there is no post-combine block)
-        const float4* dhm = npost > 0 ? dy_post(2) : dy_post(0);
+        const StashRef dhm = npost > 0 ? dy_post(2) : dy_post(0);
         for (int v = 0; v < a.NS && nvb > 0; ++v) {
             if (v > 0) acc_load<NT, MT>(dh, dhm, wave, lane);
             for (int b = nvb - 1; b >= 0; --b) {
