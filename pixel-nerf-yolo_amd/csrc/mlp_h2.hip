@@ -305,6 +305,43 @@ __device__ __forceinline__ void h2epilogue(f32x16 (&acc)[h2::NT][h2::MT], const 
     }
 }
 
+// Cross-view running sum slab of the workgroup (layout of mlp_core.h slab_store / slab_load: register quad q of tile
+// position p of lane l at float4 index (4 p + q) * 64 + l of the wave's part), addressed through a buffer resource: the lane's
+// offset in one VGPR instead of 16 hoisted (and spilled) 64-bit addresses.  Non-temporal (aux = 2), like the fp32 kernels'.
+struct SlabRef {
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned lane_off;
+};
+__device__ __forceinline__ void h2slab_store(const f32x16 (&h)[h2::NT][h2::MT], const SlabRef& sl) {
+    using namespace h2;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = {h[nt][mt][4 * q + 0], h[nt][mt][4 * q + 1], h[nt][mt][4 * q + 2], h[nt][mt][4 * q + 3]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), sl.rsrc,
+                                                       sl.lane_off + (unsigned)(((nt * MT + mt) * 4 + q) * 64 * 16), 0, 2);
+            }
+}
+__device__ __forceinline__ void h2slab_load(f32x16 (&t)[h2::NT][h2::MT], const SlabRef& sl) {
+    using namespace h2;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(sl.rsrc, sl.lane_off, (unsigned)(((nt * MT + mt) * 4 + q) * 64 * 16), 2);
+                const f32x4 v = __builtin_bit_cast(f32x4, u);
+                t[nt][mt][4 * q + 0] = v.x;
+                t[nt][mt][4 * q + 1] = v.y;
+                t[nt][mt][4 * q + 2] = v.z;
+                t[nt][mt][4 * q + 3] = v.w;
+            }
+}
+
 template <int NT_, int MT_>
 __device__ __forceinline__ void h2zero(f32x16 (&t)[NT_][MT_]) {
 #pragma unroll
@@ -423,7 +460,8 @@ __global__ __launch_bounds__(h2::THREADS, 2) void pny_mlp_h2_kernel(const MlpArg
     float* bias_tab = reinterpret_cast<float*>(smem_raw + ACT_BYTES + TAP_BYTES);   // [b_in, b_fc0[0], b_fc1[0], b_fc0[1], ...][512]
     float4* tap_raw = reinterpret_cast<float4*>(smem_raw + lds_bytes(a.n_blocks));   // STASH only: taps addressing the raw latent
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* slab = a.scratch + (size_t)blockIdx.x * (TM * HID) + (size_t)wave * (NT * MT * 16 * 64) + 4 * lane;
+    const SlabRef slab = {__builtin_amdgcn_make_buffer_rsrc(a.scratch + (size_t)blockIdx.x * (TM * HID), 0, TM * HID * 4, 0x00020000),
+                          (unsigned)((wave * (NT * MT * 16 * 64) + 4 * lane) * 4)};
     const int nb = a.n_blocks;
     const int nvb = a.combine_layer < nb ? a.combine_layer : nb;   // >= 1 (the host only selects this kernel with a projection)
     const WStream ws = wstream(a, lane);
@@ -470,7 +508,7 @@ __global__ __launch_bounds__(h2::THREADS, 2) void pny_mlp_h2_kernel(const MlpArg
         __amdgpu_buffer_rsrc_t xr = __amdgpu_buffer_rsrc_t();
         if constexpr (STASH)
             xr = __builtin_amdgcn_make_buffer_rsrc(a.stash_x + tile * a.lay.x_tile, 0, (int)(a.lay.x_tile * 4), 0x00020000);
-        auto block_tail = [&](int blk, const H2Seg& after, const float* slab_in, int next_c0, unsigned stash_net) {
+        auto block_tail = [&](int blk, const H2Seg& after, bool slab_in, int next_c0, unsigned stash_net) {
             HS_T0();
             h2zero<NT, MT>(net);
             __syncthreads();
@@ -483,7 +521,7 @@ __global__ __launch_bounds__(h2::THREADS, 2) void pny_mlp_h2_kernel(const MlpArg
             // three exclusive continuations (the running sum of the other views and the prefetched chunk both want the
             // registers of `net`: written as one if / else chain so that the allocator never has to provide for both)
             if (slab_in) {
-                slab_load<NT, MT>(net, slab_in);
+                h2slab_load(net, slab);
                 HS_LAP(HS_EPI);
                 __syncthreads();
                 HS_LAP(HS_EPI_WAIT);
@@ -554,7 +592,7 @@ __global__ __launch_bounds__(h2::THREADS, 2) void pny_mlp_h2_kernel(const MlpArg
             HS_LAP(HS_GEMM);
             // one per-view block; the last one of a view is a call site of its own so that the compiler sees that the
             // gather buffers are dead across its fc_1 GEMM (where the other views' running sum takes those registers)
-            auto view_block = [&](int blk, const H2Seg& after, const float* slab_in, int next_c0) {
+            auto view_block = [&](int blk, const H2Seg& after, bool slab_in, int next_c0) {
                 // h += interp(lin_z[blk](latent map)): the block's 512 projected channels in 4 chunks of 128, staged in
                 // fp32 (see h2epilogue).  Chunk 0 is in buffer 0 already (issued before / underneath the previous GEMM);
                 // from here two chunks are in flight: the loads of chunk c + 1 are issued before chunk c is blended.
@@ -581,17 +619,17 @@ __global__ __launch_bounds__(h2::THREADS, 2) void pny_mlp_h2_kernel(const MlpArg
             };
 #ifdef PNY_H2_NOPREFETCH
             for (int blk = 0; blk + 1 < nvb; ++blk) {
-                view_block(blk, fc0seg(blk + 1), nullptr, -1);
+                view_block(blk, fc0seg(blk + 1), false, -1);
                 gather_issue<C, 0>(g, (blk + 1) * HID, wave);
             }
 #else
-            for (int blk = 0; blk + 1 < nvb; ++blk) view_block(blk, fc0seg(blk + 1), nullptr, (blk + 1) * HID);
+            for (int blk = 0; blk + 1 < nvb; ++blk) view_block(blk, fc0seg(blk + 1), false, (blk + 1) * HID);
 #endif
-            view_block(nvb - 1, after_view, v > 0 ? slab : nullptr, -1);
+            view_block(nvb - 1, after_view, v > 0, -1);
             if (a.NS > 1) {
                 HS_T0();
                 if (v + 1 < a.NS) {
-                    slab_store<NT, MT>(h, slab);
+                    h2slab_store(h, slab);
                 } else {
                     const float rns = 1.0f / (float)a.NS;   // (the fp32 kernel divides; one rounding more here, far inside the bar)
 #pragma unroll
@@ -611,7 +649,7 @@ __global__ __launch_bounds__(h2::THREADS, 2) void pny_mlp_h2_kernel(const MlpArg
             HS_LAP(HS_EPI_WAIT);
             h2epilogue<false, STASH>(h, entry_bias(blk), planes, wave, lane, xr, post_slot(2 * (blk - nvb)));
             HS_LAP(HS_EPI);
-            block_tail(blk, blk + 1 < nb ? fc0seg(blk + 1) : s_in, nullptr, -1, post_slot(2 * (blk - nvb) + 1));
+            block_tail(blk, blk + 1 < nb ? fc0seg(blk + 1) : s_in, false, -1, post_slot(2 * (blk - nvb) + 1));
         }
         // out = lin_out(relu(h + b_fc1[last])) (reference resnetfc.py:185) + output head (models.py:312-317)
         HS_T0();
