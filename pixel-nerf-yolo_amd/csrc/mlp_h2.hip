@@ -617,7 +617,7 @@ __global__ __launch_bounds__(h2::THREADS, 2) void pny_mlp_h2_kernel(const MlpArg
                 HS_LAP(HS_EPI);
                 block_tail(blk, after, slab_in, next_c0, act_slot(2 * blk + 1));
             };
-#ifdef PNY_H2_NOPREFETCH
+#if defined(PNY_H2_NOPREFETCH)
             for (int blk = 0; blk + 1 < nvb; ++blk) {
                 view_block(blk, fc0seg(blk + 1), false, -1);
                 gather_issue<C, 0>(g, (blk + 1) * HID, wave);
