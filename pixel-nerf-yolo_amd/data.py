@@ -6,8 +6,9 @@ Host-side Python mirroring the reference's interface (same class names, construc
   SRNDataset   reference src/data/SRNDataset.py:10-136
   YOLODataset  reference src/data/YOLODataset.py:10-225 (incl. the anchor / cell target assignment)
   DVRDataset   reference src/data/DVRDataset.py:11-275 (ShapeNet / NMR renderings and the DTU sub-format)
+  MultiObjectDataset  reference src/data/MultiObjectDataset.py:14-117 (scenes of several ShapeNet objects, NeRF-style transforms.json)
   ColorJitterDataset  reference src/data/data_util.py:13-55 (training-time augmentation of ``dvr_dtu`` and ``yolo``)
-  get_split_dataset  reference src/data/__init__.py:12-76 (types ``srn``, ``dvr``, ``dvr_gen``, ``dvr_dtu`` and ``yolo``)
+  get_split_dataset  reference src/data/__init__.py:12-76 (types ``srn``, ``multi_obj``, ``dvr``, ``dvr_gen``, ``dvr_dtu`` and ``yolo``)
   psnr / ssim / write_views  what eval/eval.py:291-359 does with skimage / imageio
 
 PARITY UNPINNED against the third-party libraries the reference uses here -- imageio (decoding), cv2 (resize, projection-
@@ -227,10 +228,12 @@ class YOLODataset(torch.utils.data.Dataset):
 
 def get_split_dataset(dataset_type, datadir, want_split="all", training=True, **kwargs):
     """reference src/data/__init__.py:12-76: dataset class + flags per type name; the training split of ``dvr_dtu`` and
-    ``yolo`` is wrapped in the colour-jitter augmentation.  (``multi_obj`` is not implemented.)"""
+    ``yolo`` is wrapped in the colour-jitter augmentation."""
     flags, aug, aug_flags = {}, None, {}
     if dataset_type == "srn":
         dset_class = SRNDataset
+    elif dataset_type == "multi_obj":
+        dset_class = MultiObjectDataset
     elif dataset_type.startswith("dvr"):
         dset_class = DVRDataset
         if dataset_type == "dvr_gen":
@@ -245,7 +248,7 @@ def get_split_dataset(dataset_type, datadir, want_split="all", training=True, **
         flags["z_near"], flags["z_far"] = 1, 13.0
         aug = ColorJitterDataset
     else:
-        raise NotImplementedError("dataset type %r is not implemented here (srn, dvr, dvr_gen, dvr_dtu, yolo)" % dataset_type)
+        raise NotImplementedError("dataset type %r is not implemented here (srn, multi_obj, dvr, dvr_gen, dvr_dtu, yolo)" % dataset_type)
     want_train = want_split not in ("val", "test")
     want_val = want_split not in ("train", "test")
     want_test = want_split not in ("train", "val")
@@ -378,6 +381,64 @@ class DVRDataset(torch.utils.data.Dataset):
         else:
             item["bbox"] = bbox
         return item
+
+
+# ------------------------------------------------------------------ multi-object scenes
+class MultiObjectDataset(torch.utils.data.Dataset):
+    """<root>/<stage>/**/transforms.json (camera_angle_x, frames[file_path, transform_matrix]) with <basename>_obj.png RGBA
+    renderings beside it.  Item = {path, img_id, focal, images (NV, 3, H, W) composited on white, masks (NV, 1, H, W) = alpha,
+    bbox (NV, 4) of the non-empty pixels, poses (NV, 4, 4)}; an instance whose view count differs from ``n_views`` yields {}."""
+
+    def __init__(self, path, stage="train", z_near=4, z_far=9, n_views=None):
+        super().__init__()
+        self.base_path = os.path.join(path, stage)
+        self.trans_files = sorted(os.path.join(root, "transforms.json") for root, _, files in os.walk(self.base_path)
+                                  if "transforms.json" in files)
+        self.image_to_tensor, self.mask_to_tensor = image_to_tensor_balanced, mask_to_tensor
+        self.z_near, self.z_far, self.lindisp, self.n_views = z_near, z_far, False, n_views
+
+    def __len__(self):
+        return len(self.trans_files)
+
+    def _check_valid(self, index):
+        if self.n_views is None:
+            return True
+        import json
+        trans_file = self.trans_files[index]
+        try:
+            with open(trans_file) as fh:
+                transform = json.load(fh)
+        except Exception:
+            return False
+        return (len(transform["frames"]) == self.n_views and
+                len(glob.glob(os.path.join(os.path.dirname(trans_file), "*.png"))) == self.n_views)
+
+    def __getitem__(self, index):
+        import json
+        if not self._check_valid(index):
+            return {}
+        trans_file = self.trans_files[index]
+        dir_path = os.path.dirname(trans_file)
+        with open(trans_file) as fh:
+            transform = json.load(fh)
+        imgs, masks, bboxes, poses = [], [], [], []
+        for frame in transform["frames"]:
+            base = os.path.splitext(os.path.basename(frame["file_path"]))[0]
+            img = imread(os.path.join(dir_path, base + "_obj.png"))
+            mask = self.mask_to_tensor(img[..., 3:4])
+            rows, cols = np.where(np.any(img, axis=(1, 2)))[0], np.where(np.any(img, axis=(0, 2)))[0]
+            if len(rows) == 0:
+                box = [0, 0, mask.shape[-1], mask.shape[-2]]
+            else:
+                box = [cols[0], rows[0], cols[-1], rows[-1]]
+            bboxes.append(torch.tensor(box, dtype=torch.float32))
+            imgs.append(self.image_to_tensor(img[..., :3]) * mask + (1.0 - mask))     # white where transparent
+            masks.append(mask)
+            poses.append(torch.tensor(frame["transform_matrix"]))
+        images = torch.stack(imgs)
+        focal = 0.5 * images.shape[-1] / np.tan(0.5 * transform.get("camera_angle_x"))
+        return {"path": dir_path, "img_id": index, "focal": focal, "images": images, "masks": torch.stack(masks),
+                "bbox": torch.stack(bboxes), "poses": torch.stack(poses)}
 
 
 # ------------------------------------------------------------------ colour jitter (training-time augmentation)

@@ -238,3 +238,34 @@ def test_colour_adjustments_follow_their_definitions():
         want = colorsys.hsv_to_rgb((h + 0.07) % 1.0, s, v)
         got = pdata.adjust_hue(torch.tensor([r, gg, b]).view(3, 1, 1), 0.07).flatten().tolist()
         assert np.allclose(got, want, atol=1e-6)
+
+
+def test_multi_object_dataset_contract(tmp_path):
+    import json
+    root = str(tmp_path)
+    d = os.path.join(root, "val", "scene0")
+    os.makedirs(d)
+    rs = np.random.RandomState(4)
+    frames, truth = [], []
+    for v in range(3):
+        img = np.zeros((10, 12, 4), np.uint8)                         # transparent background
+        img[2 + v:7, 3:9 + v, :3] = rs.randint(1, 255, size=(5 - v, 6 + v, 3))
+        img[2 + v:7, 3:9 + v, 3] = 255
+        pdata.imwrite(os.path.join(d, "r_%d_obj.png" % v), img)
+        pose = synth.pose_spherical(30.0 * v, -25.0, 6.0)
+        frames.append({"file_path": "./r_%d" % v, "transform_matrix": pose.tolist()})
+        truth.append((img, pose))
+    with open(os.path.join(d, "transforms.json"), "w") as fh:
+        json.dump({"camera_angle_x": 0.8, "frames": frames}, fh)
+    ds = pdata.get_split_dataset("multi_obj", root, want_split="val", training=False)
+    assert isinstance(ds, pdata.MultiObjectDataset) and len(ds) == 1 and (ds.z_near, ds.z_far) == (4, 9)
+    it = ds[0]
+    assert it["images"].shape == (3, 3, 10, 12) and it["masks"].shape == (3, 1, 10, 12) and it["poses"].shape == (3, 4, 4)
+    assert abs(it["focal"] - 0.5 * 12 / np.tan(0.4)) < 1e-9
+    assert it["bbox"][1].tolist() == [3.0, 3.0, 9.0, 6.0]
+    img1 = torch.from_numpy(truth[1][0])
+    want = (img1[..., :3].permute(2, 0, 1).float() / 255 * 2 - 1) * (img1[..., 3] / 255.0) + (1 - img1[..., 3] / 255.0)
+    assert torch.allclose(it["images"][1], want)                      # object over white
+    assert float(it["images"][1][:, 0, 0].min()) == 1.0
+    assert np.allclose(it["poses"][2].numpy(), truth[2][1], atol=1e-6)
+    assert pdata.MultiObjectDataset(root, stage="val", n_views=2)[0] == {}     # view-count filter
