@@ -21,7 +21,14 @@
 //     block entry needs no barrier between reading the projection and writing the planes;
 //   * biases are applied lazily in the epilogue that follows (b_in + b_z0 and b_fc1[b-1] + b_z[b] at the next block entry,
 //     b_fc0 in the relu(net) epilogue, the last b_fc1 before lin_out) from a table in the remaining LDS (22 KiB for 5 blocks;
-//     152 of the CU's 160 KiB in use): no bias registers, no global loads between a barrier and a GEMM.  (mean over views of (h_v + b) = mean(h_v) + b, so the last per-view bias may follow the mean.)
+//     152 of the CU's 160 KiB in use): no bias registers, no global loads between a barrier and a GEMM.  (mean over views
+//     of (h_v + b) = mean(h_v) + b, so the last per-view bias may follow the mean.)
+//   * the projected channels of a block arrive in 4 chunks of 128 through two register buffers, the first chunk of the next
+//     block fetched underneath the fc_1 GEMM (in the registers of the then-dead `net` accumulators);
+//   * stash / slab traffic goes through raw buffer resources (one VGPR of lane offset instead of per-quad 64-bit pointers).
+// STASH = true is the training forward (the backward's operand stash written from prologue and epilogues).
+// This file is compiled with -fno-slp-vectorize (csrc/Makefile).  Phase timing: -DPNY_H2_STAMP
+// (tools/h2_variant_build.sh).
 #include <cstdlib>
 #include <cstring>
 #include <cstdio>
