@@ -101,19 +101,26 @@ def clean_points(sc, xyz, vd, n):
     return idx.numpy()
 
 
-def clean_rays(sc, rays, kc, kf, kfd, draws, n, **kw):
-    """First n of the candidate rays all of whose samples (coarse and fine pass) are unambiguous."""
-    orc.RELU_TRACE = []
-    with torch.no_grad():
-        orc.render(sc, rays, kc, kf, kfd, draws["u_coarse"], draws["u_fine"], draws["u_fine2"], draws["g_depth"], **kw)
-    N = rays.shape[0]
-    ok = torch.ones(N, dtype=torch.bool)
-    for t in orc.RELU_TRACE:                       # (N*K,) per traced relu; K = kc or kc + kf
-        ok &= t.reshape(N, -1).min(dim=1)[0] >= AMBIG
-    orc.RELU_TRACE = None
-    idx = ok.nonzero().flatten()[:n]
-    assert idx.numel() == n, "not enough unambiguous rays (%d of %d)" % (int(ok.sum()), N)
-    return idx.numpy()
+def clean_rays(sc, rays, kc, kf, kfd, draws, n, chunk=160, **kw):
+    """First n of the candidate rays all of whose samples (coarse and fine pass) are unambiguous.  Rays are independent in the
+    oracle, so the candidates are traced chunk by chunk and the search stops once n are found (the oracle on the CPU is what
+    these tests spend their time in)."""
+    found, N = [], rays.shape[0]
+    for lo in range(0, N, chunk):
+        hi = min(N, lo + chunk)
+        orc.RELU_TRACE = []
+        kw_c = {k: (v[lo:hi] if hasattr(v, "shape") and len(v.shape) > 0 and v.shape[0] == N else v) for k, v in kw.items()}
+        with torch.no_grad():
+            orc.render(sc, rays[lo:hi], kc, kf, kfd, draws["u_coarse"][lo:hi], draws["u_fine"][lo:hi], draws["u_fine2"][lo:hi],
+                       draws["g_depth"][lo:hi], **kw_c)
+        ok = torch.ones(hi - lo, dtype=torch.bool)
+        for t in orc.RELU_TRACE:                   # (n*K,) per traced relu; K = kc or kc + kf
+            ok &= t.reshape(hi - lo, -1).min(dim=1)[0] >= AMBIG
+        orc.RELU_TRACE = None
+        found += (ok.nonzero().flatten() + lo).tolist()
+        if len(found) >= n:
+            return np.asarray(found[:n])
+    raise AssertionError("not enough unambiguous rays (%d of %d)" % (len(found), N))
 
 
 # --------------------------------------------------------------------------- MLP (query) backward

@@ -132,7 +132,7 @@ def test_encoder_unit_golden(golden):
 def test_c5_eight_scenes_vs_oracle(projection):
     """BASELINE config 5 (eval over a batch of 8 objects, 3 views each, L = 1792, 64 + 32): one encode of the
     super-batch, one render call over (SB = 8, B) rays; every scene against the oracle on its own ray subset."""
-    SB, NS, H, W, B = 8, 3, 128, 128, 24
+    SB, NS, H, W, B = 8, 3, 128, 128, 12
     kc, kf, kfd = 64, 32, 16
     net = make_model(c3_conf()["model"]).eval()
     load_mlp(net.mlp_coarse, 91, 1792, 4)
