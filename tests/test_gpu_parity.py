@@ -580,6 +580,37 @@ def test_f16x2_stress_deterministic_and_close_to_f32(golden, monkeypatch):
     assert float((outs["f32"] - outs["f16x2"]).abs().max()) < 2e-5
 
 
+@pytest.mark.parametrize("n_blocks,expect_f16x2", [(6, True), (7, False), (2, True)])
+def test_f16x2_block_count_limits(n_blocks, expect_f16x2, monkeypatch):
+    """The f16x2 kernel keeps every bias of the MLP in LDS: 6 residual blocks is the most that fits the CU's 160 KiB beside the
+    128 KiB activation buffer (mlp_h2.hip MAX_NB); a 7-block model runs the fp32 kernel on the same projected maps.  Both
+    against the reference operation order on the same points."""
+    monkeypatch.setenv("PNYOLO_MLP_PRECISION", "auto")
+    c = pconf.default_mv()
+    cl = min(3, n_blocks - 1)
+    c.d["model"]["mlp_coarse"] = {"type": "resnet", "n_blocks": n_blocks, "d_hidden": 512, "d_out": 4, "combine_layer": cl}
+    c.d["model"]["mlp_fine"] = {"type": "empty"}
+    net = make_model(c["model"]).eval()
+    sd = synth.mlp_state(4000 + n_blocks, n_blocks=n_blocks, combine_layer=cl)
+    net.mlp_coarse.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    net = net.to(DEV)
+    ns, H, W = 3, 32, 32
+    net.encode(torch.zeros(1, ns, 3, H, W), torch.from_numpy(synth.scene_cameras(ns)[0])[None], torch.tensor(30.0),
+               latent=torch.from_numpy(synth.latent(4100 + n_blocks, ns, 512, H // 2, W // 2)))
+    rs = np.random.RandomState(n_blocks)
+    xyz = dt(rs.uniform(-0.5, 0.5, size=(5000, 3)).astype(np.float32))
+    vd = dt(rs.standard_normal((5000, 3)).astype(np.float32))
+    out = {}
+    for mode in ("on", "off"):
+        net.set_latent_projection(mode)
+        with torch.no_grad():
+            out[mode] = net(xyz[None], coarse=True, viewdirs=vd[None])[0]
+        if mode == "on":
+            assert net.last_launch_f16x2() == expect_f16x2 and net.last_mlp_stats(full=True)["projected"]
+    scale = max(1.0, float(out["off"][:, 3].max()))
+    assert maxabs(out["on"][:, :3], out["off"][:, :3]) < TOL and maxabs(out["on"][:, 3], out["off"][:, 3]) < TOL * scale
+
+
 def test_projection_error_is_fp32_conditioning(golden, monkeypatch):
     """On a badly conditioned scene (latent scaled x80 like a random-weight encoder's output: hidden
     activations ~1e3, sigma ~1e3) NO fp32 evaluation order reproduces another to 1e-4 absolute.  Measured
