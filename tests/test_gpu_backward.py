@@ -658,7 +658,8 @@ def test_encoder_training_gradients_vs_oracle_autograd():
 
 
 @pytest.mark.f16x2_forward
-def test_f16x2_training_forward_against_fp32_training_forward(monkeypatch):
+@pytest.mark.parametrize("L", [512, 1792])
+def test_f16x2_training_forward_against_fp32_training_forward(L, monkeypatch):
     """The default training forward (f16x2 kernel, STASH instantiation of mlp_h2.hip: projected latent, the backward's
     operands written from its epilogues) against the fp32 reference-order forward on the same super-batch: rendered values
     within 1e-4, and every parameter gradient within 0.5 % of the tensor's norm (observed: 6e-5 for the block weights, 6e-4 for
@@ -670,12 +671,15 @@ def test_f16x2_training_forward_against_fp32_training_forward(monkeypatch):
     grads, outs, used = {}, {}, {}
     for prec in ("f32", "f16x2"):
         monkeypatch.setenv("PNYOLO_MLP_PRECISION", prec)
-        net = make_model(pconf.default_mv()["model"], stop_encoder_grad=True)
-        net.mlp_coarse.load_state_dict({k: torch.from_numpy(v) for k, v in synth.mlp_state(901).items()})
-        net.mlp_fine.load_state_dict({k: torch.from_numpy(v) for k, v in synth.mlp_state(902).items()})
+        conf = pconf.default_mv()
+        if L != 512:
+            conf.d["model"]["encoder"]["backbone"] = "custom"      # d_latent = 1792: 14 chunks in the stash kernel's z gather
+        net = make_model(conf["model"], stop_encoder_grad=True)
+        net.mlp_coarse.load_state_dict({k: torch.from_numpy(v) for k, v in synth.mlp_state(901, d_latent=L).items()})
+        net.mlp_fine.load_state_dict({k: torch.from_numpy(v) for k, v in synth.mlp_state(902, d_latent=L).items()})
         net = net.to(DEV).train()
         poses = np.stack([synth.scene_cameras(ns, radius=1.3 + 0.05 * i)[0] for i in range(SB)])
-        lat = torch.from_numpy(np.concatenate([synth.latent(903 + i, ns, 512, H // 2, W // 2) for i in range(SB)]))
+        lat = torch.from_numpy(np.concatenate([synth.latent(903 + i, ns, L, H // 4, W // 4) for i in range(SB)]))
         net.encode(torch.zeros(SB, ns, 3, H, W), torch.from_numpy(poses), torch.tensor(0.9 * W), latent=lat)
         _, tgt = synth.scene_cameras(ns)
         rays_all = orc.gen_rays(tgt[None], W, H, 0.9 * W, 0.8, 1.8)[0].reshape(-1, 8)
