@@ -239,8 +239,9 @@ int pny_scene_project(pny_scene* s, pny_stream stream);
  * accumulation: the same measured error against fp64 as the fp32 matrix path (tools/ubench/split_f16_check.hip,
  * 1.7e-6 vs 1.8e-6 at K = 512 on the network's magnitudes) at 5.3x its matrix rate; held to the same 1e-4 bar by the
  * same golden vectors.  Values beyond the f16 range (|x| > 65504 in an activation or weight) are NOT representable: use
- * F32 for such models.  AUTO (default; env PNYOLO_MLP_PRECISION=f32|f16x2 overrides at scene creation) currently equals
- * F16X2: every projected launch, whatever its size, so that a ray's result does not depend on the batch it is rendered
+ * F32 for such models (AUTO does so by itself when a WEIGHT loaded at pny_model_finalize is outside the range; weights changed
+ * through pny_model_refresh and activations are not checked).  AUTO (default; env PNYOLO_MLP_PRECISION=f32|f16x2 overrides at scene creation) otherwise
+ * equals F16X2: every projected launch, whatever its size, so that a ray's result does not depend on the batch it is rendered
  * in.  Launches without projection (training forward, the reference operation order, batches below the projection
  * threshold) always run F32; models with more than 6 residual blocks or combine_layer = 0 always run F32. */
 #define PNY_PRECISION_F32 0

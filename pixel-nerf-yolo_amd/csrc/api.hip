@@ -189,6 +189,8 @@ static int pack_mlp(pny_model* m, const std::string& pre, MlpWeights& w, MlpWeig
     // split-f16 images for the f16x2 kernel (mlp_h2.hip)
     auto packed_h2 = [&](const std::string& name, int k_in, int k_pad, const float** slot) -> int {
         if ((rc = need(m, name, {HID, k_in}, &t))) return rc;
+        for (float v : t->data)
+            if (!(std::fabs(v) <= 65504.0f)) m->f16_weights_ok = false;   // out of the f16 range (or NaN): AUTO stays on fp32
         while (plan.blob.size() % 16) plan.blob.push_back(0.f);
         const size_t off = plan.blob.size();
         pack_layer_h2(t->data.data(), HID, k_in, k_pad, plan.blob);
@@ -305,6 +307,7 @@ int pny_model_finalize(pny_model* m) {
     m->repack.clear();
     m->repack_ready = false;
     PNY_HIP(hipDeviceSynchronize());  // a re-finalize must not overwrite weights a running kernel reads
+    m->f16_weights_ok = true;
     if ((rc = pack_mlp(m, "mlp_coarse.", m->coarse, m->coarse_t, plan))) return rc;
     if (m->desc.has_fine && (rc = pack_mlp(m, "mlp_fine.", m->fine, m->fine_t, plan))) return rc;
     if (plan.blob.size() * sizeof(float) >= (1ull << 31)) return fail(PNY_ERR_ARG, "packed weights exceed the 2 GiB raw-buffer range");
@@ -802,7 +805,8 @@ static int run_mlp(pny_scene* s, int mode, const float* xyz, const float* dirs, 
             // f16x2 variant of the stashing forward (mlp_h2.hip, STASH instantiation): projected latent for the forward, the
             // raw latent gathered once more per view for lin_z's weight gradient; the same stash layout and contents
             bool use_h2 = false;
-            if (s->precision != PNY_PRECISION_F32 && mlp_h2_supports(d.n_blocks, d.combine_layer) && s->L % 128 == 0) {
+            if (s->precision != PNY_PRECISION_F32 && (m->f16_weights_ok || s->precision == PNY_PRECISION_F16X2) &&
+                mlp_h2_supports(d.n_blocks, d.combine_layer) && s->L % 128 == 0) {
                 if ((rc = ensure_projection(s, fine_w ? 1 : 0, n_points, st, &a.zp, true))) return rc;
                 use_h2 = a.zp != nullptr;
                 if (use_h2) a.tap_stride = a.zp_stride;
@@ -839,7 +843,8 @@ static int run_mlp(pny_scene* s, int mode, const float* xyz, const float* dirs, 
     // f16x2 kernel (split-f16 operands, mlp_h2.hip): every projected launch unless the scene is pinned to F32 -- one
     // arithmetic for all projected launches keeps a ray's result independent of the batch it is rendered in (ray
     // sharding stays bit-exact); a lone 64-sample h2 tile is also faster than the 32-sample fp32 shape it replaces.
-    const bool use_h2 = a.zp && mlp_h2_supports(d.n_blocks, d.combine_layer) && s->precision != PNY_PRECISION_F32;
+    const bool use_h2 = a.zp && mlp_h2_supports(d.n_blocks, d.combine_layer) && s->precision != PNY_PRECISION_F32 &&
+                        (s->m->f16_weights_ok || s->precision == PNY_PRECISION_F16X2);
     if (use_h2) variant = MLP_8x64;
     const int tm = mlp_tile_samples(variant);
     const long long tiles = (n_points + tm - 1) / tm;

@@ -144,6 +144,7 @@ struct pny_model {
     ConvLayer zproj[2];
     std::vector<float*> zproj_allocs;
     bool has_zproj = false;
+    bool f16_weights_ok = true;   // every MLP weight is representable in the f16 range (checked at finalize; AUTO precision needs it)
     uint64_t generation = 0;                  // bumped by every finalize (scenes re-project)
 };
 

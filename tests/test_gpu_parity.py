@@ -611,6 +611,28 @@ def test_f16x2_block_count_limits(n_blocks, expect_f16x2, monkeypatch):
     assert maxabs(out["on"][:, :3], out["off"][:, :3]) < TOL and maxabs(out["on"][:, 3], out["off"][:, 3]) < TOL * scale
 
 
+def test_auto_precision_keeps_fp32_for_weights_outside_the_f16_range(golden, monkeypatch):
+    """A weight beyond +-65504 cannot be split into f16 planes: AUTO then stays on the fp32 kernel (checked when the weights
+    are loaded); an explicit f16x2 request is honoured."""
+    monkeypatch.setenv("PNYOLO_PROJECTION", "on")
+    monkeypatch.delenv("PNYOLO_MLP_PRECISION", raising=False)
+    g = golden("nerf_c2")
+    net = nerf_net(g, 7)
+    xyz, vd = dt(g["probe_xyz"])[None], dt(g["probe_viewdirs"])[None]
+    with torch.no_grad():
+        net(xyz, coarse=True, viewdirs=vd)
+    assert net.last_launch_f16x2()
+    with torch.no_grad():
+        net.mlp_coarse.blocks[4].fc_1.weight[3, 5] = 1.0e5
+        net.invalidate_weights()     # full re-upload: the range check runs where weights are loaded, not in the device-side refresh
+        out = net(xyz, coarse=True, viewdirs=vd)[0]
+    assert not net.last_launch_f16x2() and bool(torch.isfinite(out).all())
+    net.set_matrix_precision("f16x2")
+    with torch.no_grad():
+        net(xyz, coarse=True, viewdirs=vd)
+    assert net.last_launch_f16x2()
+
+
 def test_projection_error_is_fp32_conditioning(golden, monkeypatch):
     """On a badly conditioned scene (latent scaled x80 like a random-weight encoder's output: hidden
     activations ~1e3, sigma ~1e3) NO fp32 evaluation order reproduces another to 1e-4 absolute.  Measured
