@@ -223,7 +223,8 @@ int pny_tp_fp_fn(const float* target_boxes_dev, int nt, const float* pred_boxes_
  * weights change) and the fused kernel interpolates the projected maps instead of running the lin_z
  * GEMMs per (sample, view).  Results stay inside the 1e-4 parity tolerance (tests/test_gpu_parity.py);
  * OFF executes the reference's operation order.  AUTO (default; env PNYOLO_PROJECTION=off|on
- * overrides at scene creation) projects when a launch has >= 2x as many points as the latent has
+ * overrides at scene creation) projects every launch when the scene can use the F16X2 kernel (below), so that a ray's
+ * result does not depend on the size of its batch; otherwise when a launch has >= 2x as many points as the latent has
  * pixels per view. */
 #define PNY_PROJECTION_OFF 0
 #define PNY_PROJECTION_ON 1

@@ -696,7 +696,12 @@ int ensure_projection(pny_scene* s, int which, long long n_points, hipStream_t s
     const pny_model* m = s->m;
     if (!m->has_zproj) return 0;
     if (!force && s->zp_mode == PNY_PROJECTION_OFF) return 0;
-    if (!force && s->zp_mode == PNY_PROJECTION_AUTO && n_points < 2ll * s->hl * s->wl) return 0;
+    // AUTO: with the f16x2 kernel available every launch is projected -- a lone 64-sample tile on it (0.5 ms) beats the
+    // 32-sample fp32 shape on the unprojected latent (1.0 ms) even with the one-off projection of the scene (0.3 ms per MLP
+    // at C2), and a ray's result then never depends on the size of the batch it is rendered in.  Without it (F32 scenes,
+    // more than 6 blocks): project when the launch has at least 2x as many points as the latent has pixels per view.
+    const bool h2_ok = s->precision != PNY_PRECISION_F32 && m->f16_weights_ok && mlp_h2_supports(m->desc.n_blocks, m->desc.combine_layer);
+    if (!force && s->zp_mode == PNY_PROJECTION_AUTO && !h2_ok && n_points < 2ll * s->hl * s->wl) return 0;
     const int nvb = view_blocks(m->desc);
     if ((long long)s->hl * s->wl * nvb * HID >= (1ll << 31)) return 0;  // 32-bit tap offsets: stay direct
     if (s->zp_generation != m->generation) {

@@ -537,8 +537,13 @@ def test_projection_cache_follows_latent_and_weights(golden):
     net.mlp_fine = None
     assert maxabs(q(False), orc.query(sc3, xyz, vd, coarse=True)) < TOL
     assert net.last_mlp_stats(full=True)["projected"]
-    # 4. AUTO: 200 points < 2 x 64 x 64 latent pixels -> direct; a 9000-point launch projects
+    # 4. AUTO.  With the f16x2 kernel available every launch is projected, whatever its size; on an fp32-pinned scene the
+    #    size rule holds: 200 points < 2 x 64 x 64 latent pixels -> direct, a 9000-point launch projects
     net.set_latent_projection("auto")
+    net.set_matrix_precision("auto")
+    q(True)
+    assert net.last_mlp_stats(full=True)["projected"] and net.last_launch_f16x2()
+    net.set_matrix_precision("f32")
     q(True)
     assert not net.last_mlp_stats(full=True)["projected"]
     big = rs.uniform(-0.5, 0.5, size=(9000, 3)).astype(np.float32)
