@@ -266,6 +266,7 @@ void pny_model_destroy(pny_model* m) {
     if (!m) return;
     m->packed.release();
     m->repack_jobs.release();
+    m->d_absmax.release();
     for (int w = 0; w < 2; ++w) {
         m->dx_stash[w].release();
         m->ddy_stash[w].release();
@@ -470,7 +471,7 @@ void pny_scene_destroy(pny_scene* s) {
     s->enc_work.release();
     s->zp[0].release();
     s->zp[1].release();
-    for (DevBuf* b : {&s->x_stash, &s->dy_stash, &s->dw_partial, &s->dw_bias, &s->dw_tables, &s->d_samp, &s->out_tmp, &s->dz_tmp,
+    for (DevBuf* b : {&s->dy_absmax, &s->x_stash, &s->dy_stash, &s->dw_partial, &s->dw_bias, &s->dw_tables, &s->d_samp, &s->out_tmp, &s->dz_tmp,
                       &s->sel_tmp, &s->gdepth_tmp})
         b->release();
     for (auto e : s->ev) (void)hipEventDestroy(e);

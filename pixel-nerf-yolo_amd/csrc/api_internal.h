@@ -132,6 +132,8 @@ struct pny_model {
     DevBuf dx_stash[2], ddy_stash[2], d_partial[2], d_bias[2], d_tables[2];
     PinnedStage d_stage[2];
     long long defer_cap[2] = {0, 0}, defer_used[2] = {0, 0};
+    DevBuf d_absmax;                         // two words: running max |dY| of the deferred tiles per MLP (train_api.hip)
+    bool defer_dw_f32 = false;               // a scene pinned to F32 contributed: the flush runs the fp32 weight-gradient GEMM
     hipStream_t aux_stream = nullptr;        // side stream of the weight-gradient GEMMs' clipped tiles (mlp_bwd.hip launch_dw_gemm)
     hipEvent_t aux_fork = nullptr, aux_join = nullptr;
     uint64_t defer_epoch = 0;                // bumped by every pny_model_defer_weight_grads(enable)
@@ -174,6 +176,7 @@ struct pny_scene {
     int last_launches = 0;
     // stream the last call on this scene was enqueued on (see enter_stream)
     // training workspace (train_api.hip)
+    DevBuf dy_absmax;                        // one word: running max |dY| of the chunk in flight (non-deferred backward)
     DevBuf x_stash, dy_stash, dw_partial, dw_bias, dw_tables, d_samp, out_tmp, dz_tmp, sel_tmp, gdepth_tmp;
     PinnedStage table_stage;
     // "stash in the forward": the next pny_render evaluates the MLPs with the STASH instantiation straight into the

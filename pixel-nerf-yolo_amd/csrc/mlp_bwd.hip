@@ -78,9 +78,11 @@ __device__ __forceinline__ unsigned acc_lane_off(int wave, int lane) {
 }
 
 // act[feature/4][m] = acc (no activation): the B operand of the next transposed GEMM; optionally also to the dY stash.
+// `amax` collects max |v| over everything written to the dY stash: the split-f16 weight-gradient GEMM scales dY by a power of two
+// derived from it (pny_dw_gemm_h2_kernel).
 template <int NT, int MT, bool TO_LDS, bool TO_GLOBAL>
 __device__ __forceinline__ void store_plain(const f32x16 (&acc)[NT][MT], float4* __restrict__ act, const StashRef& g,
-                                            int wave, int lane) {
+                                            int wave, int lane, float& amax) {
     constexpr int TMc = 32 * MT;
     const int m0 = lane & 31, hh = lane >> 5;
     const unsigned lo = acc_lane_off<NT, MT>(wave, lane);
@@ -94,7 +96,11 @@ __device__ __forceinline__ void store_plain(const f32x16 (&acc)[NT][MT], float4*
                                              acc[nt][mt][4 * q + 3]);
                 const int idx = (8 * NT * wave + 8 * nt + 2 * q + hh) * TMc + 32 * mt + m0;
                 if (TO_LDS) act[idx] = v;
-                if (TO_GLOBAL) stash_st(g, lo, quad_off<NT, MT>(nt, mt, q), v);
+                if (TO_GLOBAL) {
+                    stash_st(g, lo, quad_off<NT, MT>(nt, mt, q), v);
+                    amax = fmaxf(fmaxf(amax, fabsf(v.x)), fabsf(v.y));
+                    amax = fmaxf(fmaxf(amax, fabsf(v.z)), fabsf(v.w));
+                }
             }
 }
 
@@ -144,17 +150,17 @@ template <class C>
 __device__ __forceinline__ void block_bwd(f32x16 (&dh)[C::NT][C::MT], WRing<C::WDEPTH, C::NT>& ring, const WStream& ws,
                                           const WSeg& s_fc1t, const WSeg& s_fc0t, const WSeg& after, float4* act,
                                           const StashRef& x_h, const StashRef& x_net, const StashRef& dy_dnet, const StashRef& dy_dh,
-                                          float scale, int wave, int lane) {
+                                          float scale, int wave, int lane, float& amax) {
     constexpr int NT = C::NT, MT = C::MT;
     f32x16 t[NT][MT];
     __syncthreads();  // every wave is done reading the buffer (previous GEMM)
-    store_plain<NT, MT, true, false>(dh, act, dy_dh, wave, lane);
+    store_plain<NT, MT, true, false>(dh, act, dy_dh, wave, lane, amax);
     __syncthreads();
     acc_zero<NT, MT>(t);
     gemm_run<C>(t, ring, ws, s_fc1t, s_fc0t, act, lane);
     mask_by<NT, MT>(t, x_net, wave, lane);
     __syncthreads();
-    store_plain<NT, MT, true, true>(t, act, dy_dnet, wave, lane);
+    store_plain<NT, MT, true, true>(t, act, dy_dnet, wave, lane, amax);
     __syncthreads();
     acc_zero<NT, MT>(t);
     gemm_run<C>(t, ring, ws, s_fc0t, after, act, lane);
@@ -165,7 +171,7 @@ __device__ __forceinline__ void block_bwd(f32x16 (&dh)[C::NT][C::MT], WRing<C::W
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) dh[nt][mt][r] = (dh[nt][mt][r] + t[nt][mt][r]) * scale;
-    store_plain<NT, MT, false, true>(dh, nullptr, dy_dh, wave, lane);
+    store_plain<NT, MT, false, true>(dh, nullptr, dy_dh, wave, lane, amax);
 }
 
 template <class C>
@@ -185,6 +191,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void pny_mlp_bwd_kernel(const B
     WRing<C::WDEPTH, NT> ring;
     ring_fill(ring, ws, s_out);
     const float inv_ns = 1.0f / (float)a.NS;
+    float amax = 0.f;
 
     for (long long tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         float* dy_rec = a.dy_stash + tile * a.lay.dy_tile;
@@ -230,14 +237,14 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void pny_mlp_bwd_kernel(const B
         acc_zero<NT, MT>(dh);
         gemm_run<C>(dh, ring, ws, s_out, fc1t(nb - 1), act, lane);
         mask_by<NT, MT>(dh, x_post(2 * npost), wave, lane);                 // relu(h_top) > 0
-        store_plain<NT, MT, false, true>(dh, nullptr, dy_post(0), wave, lane);  // dh_top: dY of the last block's fc_1
+        store_plain<NT, MT, false, true>(dh, nullptr, dy_post(0), wave, lane, amax);  // dh_top: dY of the last block's fc_1
 
         // ---- post-combine blocks, last to first; the first of them also applies the 1/NS of the cross-view mean
         for (int b = nb - 1; b >= nvb; --b) {
             const int i = b - nvb;
             const WSeg after = b > nvb ? fc1t(b - 1) : (nvb > 0 ? fc1t(nvb - 1) : s_out);
             block_bwd<C>(dh, ring, ws, fc1t(b), fc0t(b), after, act, x_post(2 * i), x_post(2 * i + 1), dy_post(1 + 2 * i),
-                         dy_post(2 + 2 * i), b == nvb ? inv_ns : 1.0f, wave, lane);
+                         dy_post(2 + 2 * i), b == nvb ? inv_ns : 1.0f, wave, lane, amax);
         }
         // dhm: what every view's last per-view block receives (dh_top itself when there is no post-combine block)
         const StashRef dhm = npost > 0 ? dy_post(2) : dy_post(0);
@@ -246,9 +253,14 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void pny_mlp_bwd_kernel(const B
             for (int b = nvb - 1; b >= 0; --b) {
                 const WSeg after = b > 0 ? fc1t(b - 1) : (v + 1 < a.NS ? fc1t(nvb - 1) : s_out);
                 block_bwd<C>(dh, ring, ws, fc1t(b), fc0t(b), after, act, x_act(v, 2 * b), x_act(v, 2 * b + 1),
-                             dy_view(v, 2 * b), dy_view(v, 2 * b + 1), 1.0f, wave, lane);
+                             dy_view(v, 2 * b), dy_view(v, 2 * b + 1), 1.0f, wave, lane, amax);
             }
         }
+    }
+    if (a.dy_absmax) {   // non-negative floats order like their bit patterns
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+        if (lane == 0) atomicMax(a.dy_absmax, __float_as_uint(amax));
     }
 }
 
@@ -391,6 +403,174 @@ __global__ __launch_bounds__(512, 2) void pny_dw_gemm_kernel(const DwJob* __rest
     }
 }
 
+// ---- the same GEMM on the f16 matrix cores with split fp32 operands (the arithmetic of mlp_h2.hip: x = x1 + x2 in two f16
+// planes, x1 y1 + x2 y1 + x1 y2 on v_mfma_f32_32x32x16_f16 with fp32 accumulation; 5.3x the matrix rate of the fp32 MFMA).
+// Complete 256 x 256 tiles only (every 512-wide layer); the clipped jobs (lin_in, lin_out) stay on pny_dw_gemm_kernel<false>.
+//   * The contraction runs over SAMPLES, and an f16 fragment holds 8 consecutive k of one row: a staging thread loads, for one
+//     feature quad, the 8 samples {c, c + 4, ..., c + 28} of a 32-sample half (lanes c = 0..3 adjacent: 64-byte segments),
+//     i.e. an 8 x 4 block in registers, and writes per feature ONE 16-byte vector per plane -- the transpose happens in
+//     registers.  Which 8 samples share a fragment is irrelevant as long as both operands agree (k is a dummy index).
+//   * LDS image per operand and plane: [c = 0..3][feature 0..255 (+1 pad)] x 16 bytes; a fragment read is 32 consecutive
+//     features of one c: 512 contiguous bytes.  Two buffers of (A, X) x 2 planes = 128.5 KiB, one barrier per half.
+//   * Gradients span many orders of magnitude and f16 does not: dY is multiplied by a power of two that puts the launch's
+//     max |dY| (tracked by the chain kernel, BwdArgs::dy_absmax) at 2^13..2^14, and the accumulators are multiplied by its
+//     inverse on the way out -- exact.  Elements down to 2^-27 of the maximum keep all 22 bits, smaller ones an absolute
+//     2^-38 of the maximum.
+//   * Bias gradients (column sums of dY) are taken by the staging threads from the fp32 values.
+typedef _Float16 dwh8 __attribute__((ext_vector_type(8)));
+constexpr int DWH_CS = 257;                                  // 16-byte entries per c row (256 features + 1 pad)
+constexpr int DWH_PLANE = 4 * DWH_CS;                        // entries per plane
+constexpr int DWH_BUF = 2 * 2 * DWH_PLANE;                   // entries per buffer: (A, X) x 2 planes
+constexpr size_t DWH_LDS_BYTES = (size_t)2 * DWH_BUF * 16;   // 131584
+
+__device__ __forceinline__ void dwh_split2(float a, float b, unsigned& p0, unsigned& p1) {
+    float ra, rb;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p0) : "v"(a), "v"(b));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(p0), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(p0), "v"(b));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p1) : "v"(ra), "v"(rb));
+}
+
+__global__ __launch_bounds__(512, 2) void pny_dw_gemm_h2_kernel(const DwJob* __restrict__ jobs, const DwItem* __restrict__ items,
+                                                                const float* __restrict__ x_stash,
+                                                                const float* __restrict__ dy_stash, long long x_tile,
+                                                                long long dy_tile, float* __restrict__ partial,
+                                                                float* __restrict__ bias_partial,
+                                                                const unsigned* __restrict__ dy_absmax) {
+    extern __shared__ __attribute__((aligned(16))) float dw_lds[];
+    uint4* lds = reinterpret_cast<uint4*>(dw_lds);
+    const DwItem it = items[blockIdx.x];
+    const DwJob jb = jobs[it.job];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3, hh = lane >> 5, l31 = lane & 31;
+    const int row0 = it.mt * DW_TILE, col0 = it.nt * DW_TILE;
+
+    // scale = 2^(13 - floor(log2(max |dY|))), clamped to the normal range
+    float scale = 1.0f, inv_scale = 1.0f;
+    {
+        const unsigned mb = *dy_absmax;
+        int e = (int)((mb >> 23) & 0xffu) - 127;
+        if (mb != 0u && e > -100 && e < 100) {
+            scale = __uint_as_float((unsigned)(127 + 13 - e) << 23);
+            inv_scale = __uint_as_float((unsigned)(127 - 13 + e) << 23);
+        }
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // staging role of this thread: operand (waves 0..3: A = dY, waves 4..7: X), feature quad fq of the tile, sample group c
+    const int op = wave >> 2;
+    const int fq = (tid & 255) >> 2, c = tid & 3;
+    const float sc = op == 0 ? scale : 1.0f;
+    const bool want_bias = op == 0 && it.nt == 0;
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 r[8];
+    auto fetch = [&](int h) {
+        const int tv = it.tv_lo + (h >> 1), half = h & 1;
+        const int tile = tv / jb.n_views, v = tv - tile * jb.n_views;
+        const float* rec = op == 0 ? dy_stash + (long long)tile * dy_tile + jb.a_off + (long long)v * jb.a_view
+                                   : x_stash + (long long)tile * x_tile + jb.x_off + (long long)v * jb.x_view;
+        const float4* g = reinterpret_cast<const float4*>(rec) + ((op == 0 ? row0 : col0) / 4 + fq) * 64 + 32 * half + c;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[i] = g[4 * i];
+    };
+    auto stage = [&](int b) {
+        uint4* img = lds + b * DWH_BUF + op * (2 * DWH_PLANE) + c * DWH_CS + 4 * fq;
+        if (want_bias) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {   // (asm: keeps the SLP vectoriser from packing these into v_pk_add_f32 beside the MFMAs)
+                asm("v_add_f32 %0, %1, %0" : "+v"(bs[0]) : "v"(r[i].x));
+                asm("v_add_f32 %0, %1, %0" : "+v"(bs[1]) : "v"(r[i].y));
+                asm("v_add_f32 %0, %1, %0" : "+v"(bs[2]) : "v"(r[i].z));
+                asm("v_add_f32 %0, %1, %0" : "+v"(bs[3]) : "v"(r[i].w));
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (f == 0 ? r[i].x : f == 1 ? r[i].y : f == 2 ? r[i].z : r[i].w) * sc;
+            uint4 p0, p1;
+            dwh_split2(v[0], v[1], p0.x, p1.x);
+            dwh_split2(v[2], v[3], p0.y, p1.y);
+            dwh_split2(v[4], v[5], p0.z, p1.z);
+            dwh_split2(v[6], v[7], p0.w, p1.w);
+            img[f] = p0;
+            img[DWH_PLANE + f] = p1;
+        }
+    };
+    const int n_half = 2 * (it.tv_hi - it.tv_lo);
+    if (n_half > 0) {
+        fetch(0);
+        stage(0);
+        if (n_half > 1) fetch(1);
+        __syncthreads();
+    }
+    for (int h = 0; h < n_half; ++h) {
+        const int cb = h & 1;
+        if (h + 1 < n_half) {
+            stage(cb ^ 1);                     // half h + 1: every wave left that buffer at the previous barrier
+            if (h + 2 < n_half) fetch(h + 2);
+        }
+        const uint4* pa = lds + cb * DWH_BUF + hh * DWH_CS + wr * 128 + l31;
+        const uint4* px = lds + cb * DWH_BUF + 2 * DWH_PLANE + hh * DWH_CS + wc * 64 + l31;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {       // 16 samples per step: this lane's 8 are group c = 2 st + hh
+            dwh8 a1[4], a2[4], x1[2], x2[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a1[i] = __builtin_bit_cast(dwh8, pa[2 * st * DWH_CS + 32 * i]);
+                a2[i] = __builtin_bit_cast(dwh8, pa[DWH_PLANE + 2 * st * DWH_CS + 32 * i]);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                x1[j] = __builtin_bit_cast(dwh8, px[2 * st * DWH_CS + 32 * j]);
+                x2[j] = __builtin_bit_cast(dwh8, px[DWH_PLANE + 2 * st * DWH_CS + 32 * j]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[i], x1[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[i], x1[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[i], x2[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float* P = partial + it.part_off;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int row = row0 + wr * 128 + 32 * i + 8 * (rr >> 2) + 4 * hh + (rr & 3);
+                const int col = col0 + wc * 64 + 32 * j + l31;
+                P[(long long)row * jb.x_cols + col] = acc[i][j][rr] * inv_scale;
+            }
+    if (want_bias) {   // the four lanes c = 0..3 of a feature quad hold the sums of their own samples
+        float* B = bias_partial + it.bias_off;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            float t = bs[f];
+            t += __shfl_xor(t, 1, 64);
+            t += __shfl_xor(t, 2, 64);
+            if (c == 0) B[row0 + 4 * fq + f] = t;
+        }
+    }
+}
+
 // grad (+)= sum over splits of the job's partial tiles, in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void pny_dw_reduce_kernel(const DwTarget* __restrict__ targets, const float* __restrict__ partial,
                                                             const float* __restrict__ bias_partial, int accumulate) {
@@ -419,7 +599,7 @@ __global__ __launch_bounds__(256) void pny_dw_reduce_kernel(const DwTarget* __re
 // the bulk instead of forming a tail of 60 workgroups on 256 CUs.
 void launch_dw_gemm(const DwJob* jobs_dev, const DwItem* items_dev, int n_part, int n_full, const float* x_stash,
                     const float* dy_stash, long long x_tile, long long dy_tile, float* partial, float* bias_partial, hipStream_t st,
-                    hipStream_t aux, hipEvent_t ev_fork, hipEvent_t ev_join) {
+                    hipStream_t aux, hipEvent_t ev_fork, hipEvent_t ev_join, const unsigned* dy_absmax) {
     static bool attr_set[64] = {};
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
@@ -429,6 +609,8 @@ void launch_dw_gemm(const DwJob* jobs_dev, const DwItem* items_dev, int n_part, 
                                   (int)DW_LDS_BYTES);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pny_dw_gemm_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)DW_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pny_dw_gemm_h2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)DWH_LDS_BYTES);
         attr_set[dev_] = true;
     }
     const bool fork = n_part > 0 && n_full > 0 && aux && ev_fork && ev_join;
@@ -437,7 +619,10 @@ void launch_dw_gemm(const DwJob* jobs_dev, const DwItem* items_dev, int n_part, 
     if (n_part > 0)
         hipLaunchKernelGGL(pny_dw_gemm_kernel<false>, dim3(n_part), dim3(512), DW_LDS_BYTES, sp, jobs_dev, items_dev, x_stash, dy_stash,
                            x_tile, dy_tile, partial, bias_partial);
-    if (n_full > 0)
+    if (n_full > 0 && dy_absmax)   // split-f16 matrix path (dY scaled by the tracked maximum)
+        hipLaunchKernelGGL(pny_dw_gemm_h2_kernel, dim3(n_full), dim3(512), DWH_LDS_BYTES, st, jobs_dev, items_dev + n_part, x_stash,
+                           dy_stash, x_tile, dy_tile, partial, bias_partial, dy_absmax);
+    else if (n_full > 0)
         hipLaunchKernelGGL(pny_dw_gemm_kernel<true>, dim3(n_full), dim3(512), DW_LDS_BYTES, st, jobs_dev, items_dev + n_part, x_stash,
                            dy_stash, x_tile, dy_tile, partial, bias_partial);
     if (sp != st) {

@@ -120,6 +120,7 @@ struct BwdArgs {
     long long n_points;
     int n_tiles;
     int NS, n_blocks, combine_layer, d_out, yolo;
+    unsigned* dy_absmax;              // optional: atomic max of the bit pattern of |v| over everything written to the dY stash
 };
 // One weight-gradient GEMM: C[a_rows][x_cols] = sum over (tile, view) dY_slot^T X_slot.
 struct DwJob {
@@ -172,7 +173,7 @@ void launch_yolo_aggregate_bwd(const float* raw, const float* g, long long n, in
 void launch_mlp_bwd(const BwdArgs& a, int grid, hipStream_t st);
 void launch_dw_gemm(const DwJob* jobs_dev, const DwItem* items_dev, int n_part, int n_full, const float* x_stash,
                     const float* dy_stash, long long x_tile, long long dy_tile, float* partial, float* bias_partial, hipStream_t st,
-                    hipStream_t aux, hipEvent_t ev_fork, hipEvent_t ev_join);
+                    hipStream_t aux, hipEvent_t ev_fork, hipEvent_t ev_join, const unsigned* dy_absmax = nullptr);
 void launch_dw_reduce(const DwTarget* targets_dev, int n_targets, long long max_elems, const float* partial,
                       const float* bias_partial, int accumulate, hipStream_t st);
 void launch_composite_bwd(const float* rays, const float* z, const float* samp, const float* noise, long long n, int k,

@@ -163,6 +163,26 @@ void build_items(TrainPlan& p, int n_tiles, int cus, std::vector<DwItem>& items,
     *bias_floats = boff;
 }
 
+// Matrix arithmetic of the weight-gradient GEMMs of complete tiles: the scene's precision setting (F32 pins the fp32 MFMA,
+// anything else = split f16, mlp_bwd.hip pny_dw_gemm_h2_kernel); env PNYOLO_DW_PRECISION=f32|f16x2 overrides (read at every
+// call: tests vary it).
+bool dw_use_h2(const pny_scene* s) {
+    if (const char* e = getenv("PNYOLO_DW_PRECISION")) {
+        if (!strcmp(e, "f32")) return false;
+        if (!strcmp(e, "f16x2")) return true;
+    }
+    return s->precision != PNY_PRECISION_F32;
+}
+
+// A zeroed device word (or two) for the chain kernels' atomic max
+int ensure_absmax(DevBuf& b, size_t bytes) {
+    if (b.p) return 0;
+    int rc;
+    if ((rc = b.reserve(bytes))) return rc;
+    PNY_HIP(hipMemset(b.p, 0, bytes));
+    return 0;
+}
+
 size_t stash_budget_bytes() {
     size_t v = (size_t)16 << 30;  // both stashes together; PNYOLO_STASH_GB overrides (read at every call: tests vary it)
     if (const char* e = getenv("PNYOLO_STASH_GB")) {
@@ -173,8 +193,10 @@ size_t stash_budget_bytes() {
 }
 
 // Weight-gradient GEMMs over n_tiles tiles of the two stashes + deterministic split reduction into the bound gradients.
+// dy_absmax: the chain kernels' running max |dY| of these tiles (device), or null for the fp32 matrix path
 int run_weight_grads(pny_model* m, TrainPlan& plan, int n_tiles, const float* x_stash, const float* dy_stash, DevBuf& partial,
-                     DevBuf& bias, DevBuf& tables, PinnedStage& stage, int accumulate, hipStream_t st) {
+                     DevBuf& bias, DevBuf& tables, PinnedStage& stage, int accumulate, hipStream_t st,
+                     const unsigned* dy_absmax = nullptr) {
     if (!m->aux_stream) {
         PNY_HIP(hipStreamCreateWithFlags(&m->aux_stream, hipStreamNonBlocking));
         PNY_HIP(hipEventCreateWithFlags(&m->aux_fork, hipEventDisableTiming));
@@ -204,7 +226,7 @@ int run_weight_grads(pny_model* m, TrainPlan& plan, int n_tiles, const float* x_
     char* tb = reinterpret_cast<char*>(tables.p);
     launch_dw_gemm(reinterpret_cast<const DwJob*>(tb), reinterpret_cast<const DwItem*>(tb + o_items), (int)items.size() - n_full,
                    n_full, x_stash, dy_stash, plan.lay.x_tile, plan.lay.dy_tile, partial.f(), bias.f(), st, m->aux_stream,
-                   m->aux_fork, m->aux_join);
+                   m->aux_fork, m->aux_join, dy_absmax);
     PNY_HIP(hipGetLastError());
     long long max_elems = 0;
     for (const DwTarget& t : plan.targets) max_elems = std::max(max_elems, (long long)t.rows * t.cols + t.rows);
@@ -267,6 +289,18 @@ int mlp_backward(pny_scene* s, int mode, const float* xyz, const float* dirs, co
         dy_base = s->dy_stash.f();
     }
     if ((rc = s->out_tmp.reserve((size_t)chunk_pts * d.d_out * sizeof(float)))) return rc;
+    // running max |dY| for the split-f16 weight-gradient GEMM: per model and MLP in deferred mode (every scene's chain adds
+    // to it, zeroed again by the flush), per scene otherwise (zeroed in front of every chunk's chain)
+    const bool dw_h2 = dw_use_h2(s);
+    unsigned* absmax = nullptr;
+    if (defer || have_x) {
+        if (!dw_h2) m->defer_dw_f32 = true;
+        if ((rc = ensure_absmax(m->d_absmax, 2 * sizeof(unsigned)))) return rc;
+        absmax = reinterpret_cast<unsigned*>(m->d_absmax.p) + which;
+    } else if (dw_h2) {
+        if ((rc = ensure_absmax(s->dy_absmax, sizeof(unsigned)))) return rc;
+        absmax = reinterpret_cast<unsigned*>(s->dy_absmax.p);
+    }
     auto stamp = [&]() -> int {   // kernel timing for bench.py (pny_scene_enable_timing)
         if (!s->timing) return 0;
         if ((int)s->bev.size() <= s->bev_used) {
@@ -333,6 +367,8 @@ int mlp_backward(pny_scene* s, int mode, const float* xyz, const float* dirs, co
         b.combine_layer = d.combine_layer;
         b.d_out = d.d_out;
         b.yolo = d.yolo;
+        b.dy_absmax = absmax;
+        if (absmax && !(defer || have_x)) PNY_HIP(hipMemsetAsync(absmax, 0, sizeof(unsigned), st));
         launch_mlp_bwd(b, grid, st);
         PNY_HIP(hipGetLastError());
         if ((rc = stamp())) return rc;
@@ -377,7 +413,7 @@ int mlp_backward(pny_scene* s, int mode, const float* xyz, const float* dirs, co
         // 3. weight-gradient GEMMs over the two stashes + deterministic split reduction into the bound gradients
         if (!defer && !have_x &&
             (rc = run_weight_grads(m, plan, n_tiles, x_base, dy_base, s->dw_partial, s->dw_bias, s->dw_tables, s->table_stage,
-                                   (accumulate || p0 > 0) ? 1 : 0, st)))
+                                   (accumulate || p0 > 0) ? 1 : 0, st, absmax)))
             return rc;
         if ((rc = stamp())) return rc;
     }
@@ -446,8 +482,9 @@ int pny_model_flush_weight_grads(pny_model* m, int accumulate, pny_stream stream
         PNY_HIP(hipEventRecord(m->flush_ev[2 * w], st));
         if (m->defer_used[w] > 0) {
             TrainPlan plan = build_plan(m, m->defer_ns, d.d_latent, w ? "mlp_fine." : "mlp_coarse.");
+            const unsigned* absmax = (m->d_absmax.p && !m->defer_dw_f32) ? reinterpret_cast<const unsigned*>(m->d_absmax.p) + w : nullptr;
             if ((rc = run_weight_grads(m, plan, (int)m->defer_used[w], m->dx_stash[w].f(), m->ddy_stash[w].f(), m->d_partial[w],
-                                       m->d_bias[w], m->d_tables[w], m->d_stage[w], accumulate, st)))
+                                       m->d_bias[w], m->d_tables[w], m->d_stage[w], accumulate, st, absmax)))
                 return rc;
             m->flush_flops += fwd * 64.0 * (double)m->defer_used[w];
             m->flush_launches += 1;
@@ -455,6 +492,8 @@ int pny_model_flush_weight_grads(pny_model* m, int accumulate, pny_stream stream
         PNY_HIP(hipEventRecord(m->flush_ev[2 * w + 1], st));
         m->defer_used[w] = 0;
     }
+    if (m->d_absmax.p) PNY_HIP(hipMemsetAsync(m->d_absmax.p, 0, 2 * sizeof(unsigned), st));   // the next step's chains start from 0
+    m->defer_dw_f32 = false;
     return PNY_OK;
 }
 

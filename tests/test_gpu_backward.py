@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-4
 
 
-@pytest.fixture(autouse=True)
+@pytest.fixture(autouse=True, params=["dw_f32", "dw_f16x2"])
 def training_forward_arithmetic(request, monkeypatch):
     """Which kernel writes the backward's operand stash in the training forward (scene default read at pny_scene_create):
     the comparisons with torch.autograd through the oracle pin the fp32 kernel in the reference's operation order, whose
@@ -32,6 +32,10 @@ def training_forward_arithmetic(request, monkeypatch):
     of its scale per unit.  Tests marked `f16x2_forward` check that path against the fp32 path instead."""
     if "f16x2_forward" not in request.keywords:
         monkeypatch.setenv("PNYOLO_MLP_PRECISION", "f32")
+    # Every test of this module runs twice: the weight-gradient GEMMs of complete tiles on the fp32 MFMA and on the split-f16
+    # matrix path (csrc/mlp_bwd.hip pny_dw_gemm_h2_kernel: dY scaled by the chain kernel's running maximum), the latter
+    # being the default of scenes that are not pinned to F32.  Same oracle, same tolerances.
+    monkeypatch.setenv("PNYOLO_DW_PRECISION", "f32" if request.param == "dw_f32" else "f16x2")
 
 
 def grad_check(name, got, ref, rtol=RTOL):
@@ -208,6 +212,30 @@ def test_query_backward_vs_oracle_autograd(cfg):
         compare_param_grads(net, sc, which=("mlp_coarse",) if coarse else ("mlp_fine",))
         other = net.mlp_fine if coarse else net.mlp_coarse
         assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for p in other.parameters())
+
+
+@pytest.mark.parametrize("gscale", [1e-9, 3e-4, 7e5])
+def test_weight_gradients_f16x2_any_gradient_scale(gscale, monkeypatch):
+    """The split-f16 weight-gradient GEMM multiplies dY by a power of two taken from the chain kernel's running max |dY|
+    (csrc/mlp_bwd.hip pny_dw_gemm_h2_kernel): an upstream gradient 1e-9 or 7e5 times larger gives the same gradients times
+    that factor (f16 alone has neither the range nor the denormal precision for it), and they agree with the fp32 MFMA's."""
+    n = 200
+    net, _ = scene_pair(2, 32, 40, 512, 4, 5, 3, 1234)
+    rs = np.random.RandomState(9)
+    xyz, vd = rs.uniform(-0.5, 0.5, size=(n, 3)).astype(np.float32), rs.standard_normal((n, 3)).astype(np.float32)
+    G = rs.standard_normal((n, 4)).astype(np.float32)
+
+    def grads(prec, scale):
+        monkeypatch.setenv("PNYOLO_DW_PRECISION", prec)
+        net.zero_grad()
+        out = net(dt(xyz)[None], coarse=True, viewdirs=dt(vd)[None])
+        (out[0] * dt(G * np.float32(scale))).sum().backward()
+        return {k: p.grad.detach().clone() for k, p in net.mlp_coarse.named_parameters()}
+
+    ref = grads("f32", 1.0)
+    for k, g in grads("f16x2", gscale).items():
+        m = float(ref[k].abs().max())
+        assert float((g / np.float32(gscale) - ref[k]).abs().max()) <= 2e-5 * m, k
 
 
 def test_query_backward_yolo_mode():
