@@ -226,6 +226,22 @@ static int pack_mlp(pny_model* m, const std::string& pre, MlpWeights& w, MlpWeig
         }
         plan.fix.push_back({&wt.wzT_cat, off});
     }
+    // ... and of the TRANSPOSED matrices for the f16x2 backward chain (mlp_bwd_h2.hip): W^T is (k_in x n_out), K = n_out
+    auto packed_h2T = [&](const std::string& name, int n_out, int k_in, const float** slot) -> int {
+        if ((rc = need(m, name, {n_out, k_in}, &t))) return rc;
+        std::vector<float> wtr((size_t)n_out * k_in);
+        for (int n = 0; n < n_out; ++n)
+            for (int k = 0; k < k_in; ++k) wtr[(size_t)k * n_out + n] = t->data[(size_t)n * k_in + k];
+        for (float v : t->data)
+            if (!(std::fabs(v) <= 65504.0f)) m->f16_weights_ok = false;
+        const int k_pad = n_out == HID ? HID : D_IN_PAD;
+        while (plan.blob.size() % 16) plan.blob.push_back(0.f);
+        const size_t off = plan.blob.size();
+        pack_layer_h2(wtr.data(), k_in, n_out, k_pad, plan.blob);
+        plan.fix.push_back({slot, off});
+        m->repack.push_back({PACK_H2T, name, "", off, nullptr, n_out, k_in, k_pad, 0});
+        return 0;
+    };
     if (d.d_out > D_IN_PAD) return fail(PNY_ERR_ARG, "d_out > 64");
     if ((rc = plain(pre + "lin_in.weight", {HID, d_in}, &wt.w_in_plain))) return rc;
     if ((rc = packedT(pre + "lin_out.weight", d.d_out, HID, &wt.wT_out))) return rc;
@@ -233,6 +249,12 @@ static int pack_mlp(pny_model* m, const std::string& pre, MlpWeights& w, MlpWeig
         const std::string p = pre + "blocks." + std::to_string(b);
         if ((rc = packedT(p + ".fc_0.weight", HID, HID, &wt.wT_fc0[b]))) return rc;
         if ((rc = packedT(p + ".fc_1.weight", HID, HID, &wt.wT_fc1[b]))) return rc;
+    }
+    if ((rc = packed_h2T(pre + "lin_out.weight", d.d_out, HID, &wt.h2T_out))) return rc;
+    for (int b = 0; b < d.n_blocks; ++b) {
+        const std::string p = pre + "blocks." + std::to_string(b);
+        if ((rc = packed_h2T(p + ".fc_0.weight", HID, HID, &wt.h2T_fc0[b]))) return rc;
+        if ((rc = packed_h2T(p + ".fc_1.weight", HID, HID, &wt.h2T_fc1[b]))) return rc;
     }
     return 0;
 }
@@ -398,7 +420,7 @@ int pny_model_refresh(pny_model* m, pny_stream stream) {
             j.k_pad = e.k_pad;
             if (e.kind == PACK_A || e.kind == PACK_NT || e.kind == PACK_H2)
                 j.count = (e.n_out / 32) * (e.k_pad / 8) * 64;       // 16-byte elements
-            else if (e.kind == PACK_AT)
+            else if (e.kind == PACK_AT || e.kind == PACK_H2T)
                 j.count = (e.k_in / 32) * (e.k_pad / 8) * 64;
             else if (e.kind == PACK_NTT)
                 j.count = (e.n_out / 32) * (e.k_in / 8) * 64;

@@ -19,7 +19,7 @@
 #include <cstring>
 #include <vector>
 
-#include "mlp_core.h"
+#include "mlp_bwd_core.h"
 #include "pny_rng.h"
 
 namespace pny {
@@ -29,52 +29,6 @@ __device__ __forceinline__ float bwd_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
-}
-
-__device__ __forceinline__ WStream wstream_raw(const float* base, unsigned bytes, int lane) {
-    WStream w;
-    w.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
-    w.base = reinterpret_cast<const char*>(base);
-    w.lane_off = 16u * (unsigned)lane;
-    return w;
-}
-
-template <int NT, int MT>
-__device__ __forceinline__ void acc_zero(f32x16 (&t)[NT][MT]) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) t[nt][mt][r] = 0.f;
-}
-
-// The two stashes of a tile are addressed through raw buffer resources (one per tile record, 32-bit byte offsets): a slot
-// access in accumulator layout is the lane's own offset (one VGPR for the whole kernel) + the slot's offset + a
-// compile-time constant per accumulator quad.  With 64-bit pointers every quad had its own address pair, and those spilled
-// inside the GEMM loops.  Stores keep the whole offset in the VGPR operand and the constant 0 in soffset (see mlp_h2.hip
-// stash_store: the form for which the compiler inserts the >64-bit store-data wait state).
-struct StashRef {
-    __amdgpu_buffer_rsrc_t rsrc;
-    unsigned off;   // byte offset of the slot inside the record
-};
-__device__ __forceinline__ float4 stash_ld(const StashRef& r, unsigned lane_off, unsigned c) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r.rsrc, lane_off, r.off + c, 0);
-    const f32x4 f = __builtin_bit_cast(f32x4, v);
-    return make_float4(f.x, f.y, f.z, f.w);
-}
-__device__ __forceinline__ void stash_st(const StashRef& r, unsigned lane_off, unsigned c, const float4& v) {
-    const f32x4 f = {v.x, v.y, v.z, v.w};
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f), r.rsrc, lane_off + r.off + c, 0, 0);
-}
-// byte offset of accumulator quad (nt, mt, q) relative to the lane's own offset acc_lane_off()
-template <int NT, int MT>
-__device__ __forceinline__ constexpr unsigned quad_off(int nt, int mt, int q) {
-    return (unsigned)(((8 * nt + 2 * q) * (32 * MT) + 32 * mt) * 16);
-}
-template <int NT, int MT>
-__device__ __forceinline__ unsigned acc_lane_off(int wave, int lane) {
-    return (unsigned)(((8 * NT * wave + (lane >> 5)) * (32 * MT) + (lane & 31)) * 16);
 }
 
 // act[feature/4][m] = acc (no activation): the B operand of the next transposed GEMM; optionally also to the dY stash.
@@ -101,44 +55,6 @@ __device__ __forceinline__ void store_plain(const f32x16 (&acc)[NT][MT], float4*
                     amax = fmaxf(fmaxf(amax, fabsf(v.x)), fabsf(v.y));
                     amax = fmaxf(fmaxf(amax, fabsf(v.z)), fabsf(v.w));
                 }
-            }
-}
-
-// acc = (x > 0) ? acc : 0 with x = the stashed relu'd activation of the same element (accumulator layout).
-template <int NT, int MT>
-__device__ __forceinline__ void mask_by(f32x16 (&acc)[NT][MT], const StashRef& x, int wave, int lane) {
-    const unsigned lo = acc_lane_off<NT, MT>(wave, lane);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            float4 xv[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) xv[q] = stash_ld(x, lo, quad_off<NT, MT>(nt, mt, q));
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                acc[nt][mt][4 * q + 0] = xv[q].x > 0.f ? acc[nt][mt][4 * q + 0] : 0.f;
-                acc[nt][mt][4 * q + 1] = xv[q].y > 0.f ? acc[nt][mt][4 * q + 1] : 0.f;
-                acc[nt][mt][4 * q + 2] = xv[q].z > 0.f ? acc[nt][mt][4 * q + 2] : 0.f;
-                acc[nt][mt][4 * q + 3] = xv[q].w > 0.f ? acc[nt][mt][4 * q + 3] : 0.f;
-            }
-        }
-}
-
-template <int NT, int MT>
-__device__ __forceinline__ void acc_load(f32x16 (&acc)[NT][MT], const StashRef& g, int wave, int lane) {
-    const unsigned lo = acc_lane_off<NT, MT>(wave, lane);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 v = stash_ld(g, lo, quad_off<NT, MT>(nt, mt, q));
-                acc[nt][mt][4 * q + 0] = v.x;
-                acc[nt][mt][4 * q + 1] = v.y;
-                acc[nt][mt][4 * q + 2] = v.z;
-                acc[nt][mt][4 * q + 3] = v.w;
             }
 }
 
@@ -230,7 +146,9 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void pny_mlp_bwd_kernel(const B
             }
             const float4 v4 = make_float4(v[0], v[1], v[2], v[3]);
             act[idx] = v4;
-            dy_draw[idx] = v4;
+            dy_draw[idx] = v4;   // lin_out's dY
+            amax = fmaxf(fmaxf(amax, fabsf(v[0])), fabsf(v[1]));
+            amax = fmaxf(fmaxf(amax, fabsf(v[2])), fabsf(v[3]));
         }
         __syncthreads();
         f32x16 dh[NT][MT];
@@ -405,7 +323,7 @@ __global__ __launch_bounds__(512, 2) void pny_dw_gemm_kernel(const DwJob* __rest
 
 // ---- the same GEMM on the f16 matrix cores with split fp32 operands (the arithmetic of mlp_h2.hip: x = x1 + x2 in two f16
 // planes, x1 y1 + x2 y1 + x1 y2 on v_mfma_f32_32x32x16_f16 with fp32 accumulation; 5.3x the matrix rate of the fp32 MFMA).
-// Complete 256 x 256 tiles only (every 512-wide layer); the clipped jobs (lin_in, lin_out) stay on pny_dw_gemm_kernel<false>.
+// Clipped tiles (lin_in's 64 columns, lin_out's 64 rows) run a predicated instantiation, as in the fp32 kernel.
 //   * The contraction runs over SAMPLES, and an f16 fragment holds 8 consecutive k of one row: a staging thread loads, for one
 //     feature quad, the 8 samples {c, c + 4, ..., c + 28} of a 32-sample half (lanes c = 0..3 adjacent: 64-byte segments),
 //     i.e. an 8 x 4 block in registers, and writes per feature ONE 16-byte vector per plane -- the transpose happens in
@@ -431,6 +349,7 @@ __device__ __forceinline__ void dwh_split2(float a, float b, unsigned& p0, unsig
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p1) : "v"(ra), "v"(rb));
 }
 
+template <bool FULL>   // FULL: complete 256 x 256 tiles, predicate-free; otherwise rows / columns beyond the job are zero-filled and skipped
 __global__ __launch_bounds__(512, 2) void pny_dw_gemm_h2_kernel(const DwJob* __restrict__ jobs, const DwItem* __restrict__ items,
                                                                 const float* __restrict__ x_stash,
                                                                 const float* __restrict__ dy_stash, long long x_tile,
@@ -471,6 +390,15 @@ __global__ __launch_bounds__(512, 2) void pny_dw_gemm_h2_kernel(const DwJob* __r
     const bool want_bias = op == 0 && it.nt == 0;
     float bs[4] = {0.f, 0.f, 0.f, 0.f};
     float4 r[8];
+    // clipped tiles: quads beyond the job's extent load nothing (zeros); quads beyond the last 32-wide MFMA tile that holds
+    // live data are not even written
+    const int extent = op == 0 ? jb.a_rows - row0 : jb.x_cols - col0;
+    const bool q_load = FULL || 4 * fq < extent, q_write = FULL || 4 * fq < ((extent + 31) & ~31);
+    bool live_a[4], live_x[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) live_a[i] = FULL || row0 + wr * 128 + 32 * i < jb.a_rows;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) live_x[j] = FULL || col0 + wc * 64 + 32 * j < jb.x_cols;
     auto fetch = [&](int h) {
         const int tv = it.tv_lo + (h >> 1), half = h & 1;
         const int tile = tv / jb.n_views, v = tv - tile * jb.n_views;
@@ -478,10 +406,11 @@ __global__ __launch_bounds__(512, 2) void pny_dw_gemm_h2_kernel(const DwJob* __r
                                    : x_stash + (long long)tile * x_tile + jb.x_off + (long long)v * jb.x_view;
         const float4* g = reinterpret_cast<const float4*>(rec) + ((op == 0 ? row0 : col0) / 4 + fq) * 64 + 32 * half + c;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) r[i] = g[4 * i];
+        for (int i = 0; i < 8; ++i) r[i] = q_load ? g[4 * i] : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     auto stage = [&](int b) {
         uint4* img = lds + b * DWH_BUF + op * (2 * DWH_PLANE) + c * DWH_CS + 4 * fq;
+        if (!q_write) return;
         if (want_bias) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {   // (asm: keeps the SLP vectoriser from packing these into v_pk_add_f32 beside the MFMAs)
@@ -522,29 +451,34 @@ __global__ __launch_bounds__(512, 2) void pny_dw_gemm_h2_kernel(const DwJob* __r
         const uint4* px = lds + cb * DWH_BUF + 2 * DWH_PLANE + hh * DWH_CS + wc * 64 + l31;
 #pragma unroll
         for (int st = 0; st < 2; ++st) {       // 16 samples per step: this lane's 8 are group c = 2 st + hh
-            dwh8 a1[4], a2[4], x1[2], x2[2];
+            dwh8 a1[4] = {}, a2[4] = {}, x1[2] = {}, x2[2] = {};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                a1[i] = __builtin_bit_cast(dwh8, pa[2 * st * DWH_CS + 32 * i]);
-                a2[i] = __builtin_bit_cast(dwh8, pa[DWH_PLANE + 2 * st * DWH_CS + 32 * i]);
-            }
+            for (int i = 0; i < 4; ++i)
+                if (FULL || live_a[i]) {
+                    a1[i] = __builtin_bit_cast(dwh8, pa[2 * st * DWH_CS + 32 * i]);
+                    a2[i] = __builtin_bit_cast(dwh8, pa[DWH_PLANE + 2 * st * DWH_CS + 32 * i]);
+                }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                x1[j] = __builtin_bit_cast(dwh8, px[2 * st * DWH_CS + 32 * j]);
-                x2[j] = __builtin_bit_cast(dwh8, px[DWH_PLANE + 2 * st * DWH_CS + 32 * j]);
-            }
+            for (int j = 0; j < 2; ++j)
+                if (FULL || live_x[j]) {
+                    x1[j] = __builtin_bit_cast(dwh8, px[2 * st * DWH_CS + 32 * j]);
+                    x2[j] = __builtin_bit_cast(dwh8, px[DWH_PLANE + 2 * st * DWH_CS + 32 * j]);
+                }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[i], x1[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j)
+                    if (FULL || (live_a[i] && live_x[j])) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[i], x1[j], acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[i], x1[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j)
+                    if (FULL || (live_a[i] && live_x[j])) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[i], x1[j], acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[i], x2[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j)
+                    if (FULL || (live_a[i] && live_x[j])) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[i], x2[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
     }
@@ -552,13 +486,15 @@ __global__ __launch_bounds__(512, 2) void pny_dw_gemm_h2_kernel(const DwJob* __r
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j) {
+            if (!FULL && !(live_a[i] && live_x[j])) continue;
 #pragma unroll
             for (int rr = 0; rr < 16; ++rr) {
                 const int row = row0 + wr * 128 + 32 * i + 8 * (rr >> 2) + 4 * hh + (rr & 3);
                 const int col = col0 + wc * 64 + 32 * j + l31;
-                P[(long long)row * jb.x_cols + col] = acc[i][j][rr] * inv_scale;
+                if (FULL || (row < jb.a_rows && col < jb.x_cols)) P[(long long)row * jb.x_cols + col] = acc[i][j][rr] * inv_scale;
             }
+        }
     if (want_bias) {   // the four lanes c = 0..3 of a feature quad hold the sums of their own samples
         float* B = bias_partial + it.bias_off;
 #pragma unroll
@@ -566,7 +502,7 @@ __global__ __launch_bounds__(512, 2) void pny_dw_gemm_h2_kernel(const DwJob* __r
             float t = bs[f];
             t += __shfl_xor(t, 1, 64);
             t += __shfl_xor(t, 2, 64);
-            if (c == 0) B[row0 + 4 * fq + f] = t;
+            if (c == 0 && (FULL || row0 + 4 * fq + f < jb.a_rows)) B[row0 + 4 * fq + f] = t;
         }
     }
 }
@@ -609,18 +545,23 @@ void launch_dw_gemm(const DwJob* jobs_dev, const DwItem* items_dev, int n_part, 
                                   (int)DW_LDS_BYTES);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pny_dw_gemm_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)DW_LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pny_dw_gemm_h2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pny_dw_gemm_h2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)DWH_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pny_dw_gemm_h2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)DWH_LDS_BYTES);
         attr_set[dev_] = true;
     }
     const bool fork = n_part > 0 && n_full > 0 && aux && ev_fork && ev_join;
     hipStream_t sp = st;
     if (fork && hipEventRecord(ev_fork, st) == hipSuccess && hipStreamWaitEvent(aux, ev_fork, 0) == hipSuccess) sp = aux;
-    if (n_part > 0)
+    if (n_part > 0 && dy_absmax)   // split-f16 matrix path (dY scaled by the tracked maximum)
+        hipLaunchKernelGGL(pny_dw_gemm_h2_kernel<false>, dim3(n_part), dim3(512), DWH_LDS_BYTES, sp, jobs_dev, items_dev, x_stash, dy_stash,
+                           x_tile, dy_tile, partial, bias_partial, dy_absmax);
+    else if (n_part > 0)
         hipLaunchKernelGGL(pny_dw_gemm_kernel<false>, dim3(n_part), dim3(512), DW_LDS_BYTES, sp, jobs_dev, items_dev, x_stash, dy_stash,
                            x_tile, dy_tile, partial, bias_partial);
-    if (n_full > 0 && dy_absmax)   // split-f16 matrix path (dY scaled by the tracked maximum)
-        hipLaunchKernelGGL(pny_dw_gemm_h2_kernel, dim3(n_full), dim3(512), DWH_LDS_BYTES, st, jobs_dev, items_dev + n_part, x_stash,
+    if (n_full > 0 && dy_absmax)
+        hipLaunchKernelGGL(pny_dw_gemm_h2_kernel<true>, dim3(n_full), dim3(512), DWH_LDS_BYTES, st, jobs_dev, items_dev + n_part, x_stash,
                            dy_stash, x_tile, dy_tile, partial, bias_partial, dy_absmax);
     else if (n_full > 0)
         hipLaunchKernelGGL(pny_dw_gemm_kernel<true>, dim3(n_full), dim3(512), DW_LDS_BYTES, st, jobs_dev, items_dev + n_part, x_stash,

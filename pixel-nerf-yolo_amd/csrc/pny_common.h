@@ -95,7 +95,7 @@ struct MlpArgs {
 };
 
 // ---- device-side weight repack (pack.hip): the packed operand layouts rebuilt from the live parameter tensors
-enum { PACK_A = 0, PACK_AT = 1, PACK_NT = 2, PACK_COPY = 3, PACK_ADD2 = 4, PACK_H2 = 5, PACK_NTT = 6 };
+enum { PACK_A = 0, PACK_AT = 1, PACK_NT = 2, PACK_COPY = 3, PACK_ADD2 = 4, PACK_H2 = 5, PACK_NTT = 6, PACK_H2T = 7 };
 struct PackJob {
     const float* src;
     const float* src2;
@@ -110,6 +110,10 @@ struct BwdArgs {
     const float* wT_out;              // lin_out^T: 512 x d_out, K padded to D_IN_PAD
     const float* wT_fc0[MAX_BLOCKS];
     const float* wT_fc1[MAX_BLOCKS];
+    // the same matrices as split-f16 images (mlp_bwd_h2.hip; api.hip pack_mlp PACK_H2T); null when the fp32 chain runs
+    const float* h2T_out;
+    const float* h2T_fc0[MAX_BLOCKS];
+    const float* h2T_fc1[MAX_BLOCKS];
     const float* w_base;
     unsigned w_bytes;
     const float* x_stash;             // written by the STASH forward
@@ -171,6 +175,7 @@ void launch_mlp_dz(const DzArgs& a, hipStream_t st);
 void launch_depth_grad_gather(const int* sel, const float* dz, const float* g_in, long long n, int kfd, float* g_out, hipStream_t st);
 void launch_yolo_aggregate_bwd(const float* raw, const float* g, long long n, int k, int na, float* d_raw, hipStream_t st);
 void launch_mlp_bwd(const BwdArgs& a, int grid, hipStream_t st);
+void launch_mlp_bwd_h2(const BwdArgs& a, int grid, hipStream_t st);   // mlp_bwd_h2.hip: needs a.h2T_*
 void launch_dw_gemm(const DwJob* jobs_dev, const DwItem* items_dev, int n_part, int n_full, const float* x_stash,
                     const float* dy_stash, long long x_tile, long long dy_tile, float* partial, float* bias_partial, hipStream_t st,
                     hipStream_t aux, hipEvent_t ev_fork, hipEvent_t ev_join, const unsigned* dy_absmax = nullptr);

@@ -163,11 +163,11 @@ void build_items(TrainPlan& p, int n_tiles, int cus, std::vector<DwItem>& items,
     *bias_floats = boff;
 }
 
-// Matrix arithmetic of the weight-gradient GEMMs of complete tiles: the scene's precision setting (F32 pins the fp32 MFMA,
-// anything else = split f16, mlp_bwd.hip pny_dw_gemm_h2_kernel); env PNYOLO_DW_PRECISION=f32|f16x2 overrides (read at every
-// call: tests vary it).
+// Matrix arithmetic of the backward's GEMMs (dX chain and weight gradients): the scene's precision setting (F32 pins the fp32
+// MFMA; anything else = split f16: mlp_bwd_h2.hip pny_mlp_bwd_h2_kernel, mlp_bwd.hip pny_dw_gemm_h2_kernel); env
+// PNYOLO_BWD_PRECISION=f32|f16x2 overrides (read at every call: tests vary it).
 bool dw_use_h2(const pny_scene* s) {
-    if (const char* e = getenv("PNYOLO_DW_PRECISION")) {
+    if (const char* e = getenv("PNYOLO_BWD_PRECISION")) {
         if (!strcmp(e, "f32")) return false;
         if (!strcmp(e, "f16x2")) return true;
     }
@@ -369,7 +369,16 @@ int mlp_backward(pny_scene* s, int mode, const float* xyz, const float* dirs, co
         b.yolo = d.yolo;
         b.dy_absmax = absmax;
         if (absmax && !(defer || have_x)) PNY_HIP(hipMemsetAsync(absmax, 0, sizeof(unsigned), st));
-        launch_mlp_bwd(b, grid, st);
+        if (dw_h2 && m->f16_weights_ok) {   // split-f16 chain (weights beyond the f16 range: fp32 chain)
+            b.h2T_out = wt.h2T_out;
+            for (int i = 0; i < d.n_blocks; ++i) {
+                b.h2T_fc0[i] = wt.h2T_fc0[i];
+                b.h2T_fc1[i] = wt.h2T_fc1[i];
+            }
+            launch_mlp_bwd_h2(b, grid, st);
+        } else {
+            launch_mlp_bwd(b, grid, st);
+        }
         PNY_HIP(hipGetLastError());
         if ((rc = stamp())) return rc;
         // 2b. gradient w.r.t. the depths of the selected samples through the MLP inputs (fine pass of a render)

@@ -35,7 +35,7 @@ def training_forward_arithmetic(request, monkeypatch):
     # Every test of this module runs twice: the weight-gradient GEMMs of complete tiles on the fp32 MFMA and on the split-f16
     # matrix path (csrc/mlp_bwd.hip pny_dw_gemm_h2_kernel: dY scaled by the chain kernel's running maximum), the latter
     # being the default of scenes that are not pinned to F32.  Same oracle, same tolerances.
-    monkeypatch.setenv("PNYOLO_DW_PRECISION", "f32" if request.param == "dw_f32" else "f16x2")
+    monkeypatch.setenv("PNYOLO_BWD_PRECISION", "f32" if request.param == "dw_f32" else "f16x2")
 
 
 def grad_check(name, got, ref, rtol=RTOL):
@@ -226,7 +226,7 @@ def test_weight_gradients_f16x2_any_gradient_scale(gscale, monkeypatch):
     G = rs.standard_normal((n, 4)).astype(np.float32)
 
     def grads(prec, scale):
-        monkeypatch.setenv("PNYOLO_DW_PRECISION", prec)
+        monkeypatch.setenv("PNYOLO_BWD_PRECISION", prec)
         net.zero_grad()
         out = net(dt(xyz)[None], coarse=True, viewdirs=dt(vd)[None])
         (out[0] * dt(G * np.float32(scale))).sum().backward()
