@@ -736,7 +736,8 @@ int ensure_projection(pny_scene* s, int which, long long n_points, hipStream_t s
         const long long npix = (long long)s->ns * s->hl * s->wl;
         int rc;
         if ((rc = s->zp[which].reserve((size_t)npix * nvb * HID * sizeof(float)))) return rc;
-        if (!run_pixel_linear(m->zproj[which], s->latent.f(), npix, s->zp[which].f(), st))
+        // scenes whose projected launches run the f16x2 kernel project on the split-f16 matrix path too
+        if (!run_pixel_linear(m->zproj[which], s->latent.f(), npix, s->zp[which].f(), st, h2_ok))
             return fail(PNY_ERR_HIP, "latent projection launch failed");
         s->zp_valid[which] = true;
     }
@@ -1069,6 +1070,7 @@ int pny_scene_set_precision(pny_scene* s, int mode) {
     if (!s) return fail(PNY_ERR_ARG, "pny_scene_set_precision: null scene");
     if (mode != PNY_PRECISION_F32 && mode != PNY_PRECISION_F16X2 && mode != PNY_PRECISION_AUTO)
         return fail(PNY_ERR_ARG, "pny_scene_set_precision: mode must be PNY_PRECISION_{F32,F16X2,AUTO}");
+    if ((mode == PNY_PRECISION_F32) != (s->precision == PNY_PRECISION_F32)) s->zp_valid[0] = s->zp_valid[1] = false;   // re-project in the new arithmetic
     s->precision = mode;
     return PNY_OK;
 }

@@ -35,7 +35,8 @@ struct EncoderWeights {
 // row-major (rows x k) matrices stacked along n; rows*nmat must be a multiple of 64, k of 8.
 bool build_pixel_linear(const float* const* mats, int nmat, int rows, int k, ConvLayer* out, std::vector<float*>* allocs,
                         std::string* err);
-bool run_pixel_linear(const ConvLayer& L, const float* in, long long npix, float* out, hipStream_t st);
+// f16x2: split-f16 matrix products (pixel_linear_h2_kernel) instead of the fp32 MFMA
+bool run_pixel_linear(const ConvLayer& L, const float* in, long long npix, float* out, hipStream_t st, bool f16x2 = false);
 
 void encoder_latent_size(int height, int width, int* hl, int* wl);
 size_t encoder_workspace_bytes(int ns, int height, int width, bool use_first_pool);

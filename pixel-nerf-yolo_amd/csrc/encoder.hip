@@ -295,6 +295,133 @@ __global__ __launch_bounds__(64 * PL_NW) void pixel_linear_kernel(const float* _
     }
 }
 
+// The same GEMM on the f16 matrix cores with split fp32 operands (the arithmetic of mlp_h2.hip: x = x1 + x2 in two f16 planes,
+// x1 w1 + x2 w1 + x1 w2 on v_mfma_f32_32x32x16_f16, fp32 accumulation), for scenes whose MLP launches run the f16x2 kernels:
+// in a training step the projection is redone for every scene and MLP after each optimizer step.  Same tiling and the same
+// packed fp32 weights: a 16-k step takes the lane's OWN two float4 of the fp32 image (k = 16 J + 4 hh + 0..3 and
+// 16 J + 8 + 4 hh + 0..3 -- which 8 k a fragment holds is free as long as both operands agree) and splits them in
+// registers; the pixel operand is split once, on its way into LDS ([plane][k / 4][pixel] x 8 bytes).
+typedef _Float16 plh8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void pl_split2(float a, float b, unsigned& p0, unsigned& p1) {
+    float ra, rb;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p0) : "v"(a), "v"(b));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(p0), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(p0), "v"(b));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p1) : "v"(ra), "v"(rb));
+}
+
+__global__ __launch_bounds__(64 * PL_NW) void pixel_linear_h2_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                                     float* __restrict__ out, long long npix, int K, int cout) {
+    __shared__ uint2 bp[2][2][PL_KC / 4][PL_PIX + 1];  // [buffer][plane][k / 4][pixel]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = lane & 31, hh = lane >> 5;
+    const int nblocks = cout / 256;
+    const long long pb = blockIdx.x / nblocks;
+    const int nb = (int)(blockIdx.x - pb * nblocks);
+    const long long p0 = pb * PL_PIX;
+    const int J = K / 8;
+    const int srow = tid >> 2, sq = (tid & 3) * 2;
+    auto stage_load = [&](int c, float4 (&v)[2][2]) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            long long p = p0 + srow + 64 * r;
+            if (p >= npix) p = npix - 1;
+            const float4* src = reinterpret_cast<const float4*>(in + (size_t)p * K + (size_t)c * PL_KC) + sq;
+            v[r][0] = src[0];
+            v[r][1] = src[1];
+        }
+    };
+    auto stage_store = [&](int buf, const float4 (&v)[2][2]) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                uint2 q0, q1;
+                pl_split2(v[r][h].x, v[r][h].y, q0.x, q1.x);
+                pl_split2(v[r][h].z, v[r][h].w, q0.y, q1.y);
+                bp[buf][0][sq + h][srow + 64 * r] = q0;
+                bp[buf][1][sq + h][srow + 64 * r] = q1;
+            }
+    };
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.f;
+    const int nt0 = nb * 8 + wave * 2;
+    const float4* wp = reinterpret_cast<const float4*>(w) + (size_t)nt0 * J * 64 + lane;
+    const int nchunks = K / PL_KC;
+    float4 sv[2][2];
+    stage_load(0, sv);
+    stage_store(0, sv);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) stage_load(c + 1, sv);
+        float4 a[PL_KC / 8][2];
+#pragma unroll
+        for (int j = 0; j < PL_KC / 8; ++j)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) a[j][nt] = wp[((size_t)nt * J + (size_t)c * (PL_KC / 8) + j) * 64];
+#pragma unroll
+        for (int s = 0; s < PL_KC / 16; ++s) {
+            plh8 a1[2], a2[2], b1[4], b2[4];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                uint4 u1, u2;
+                pl_split2(a[2 * s][nt].x, a[2 * s][nt].y, u1.x, u2.x);
+                pl_split2(a[2 * s][nt].z, a[2 * s][nt].w, u1.y, u2.y);
+                pl_split2(a[2 * s + 1][nt].x, a[2 * s + 1][nt].y, u1.z, u2.z);
+                pl_split2(a[2 * s + 1][nt].z, a[2 * s + 1][nt].w, u1.w, u2.w);
+                a1[nt] = __builtin_bit_cast(plh8, u1);
+                a2[nt] = __builtin_bit_cast(plh8, u2);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const uint2 l1 = bp[buf][0][4 * s + hh][32 * mt + m0], h1 = bp[buf][0][4 * s + 2 + hh][32 * mt + m0];
+                const uint2 l2 = bp[buf][1][4 * s + hh][32 * mt + m0], h2 = bp[buf][1][4 * s + 2 + hh][32 * mt + m0];
+                b1[mt] = __builtin_bit_cast(plh8, make_uint4(l1.x, l1.y, h1.x, h1.y));
+                b2[mt] = __builtin_bit_cast(plh8, make_uint4(l2.x, l2.y, h2.x, h2.y));
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[nt], b1[mt], acc[nt][mt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[nt], b1[mt], acc[nt][mt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[nt], b2[mt], acc[nt][mt], 0, 0, 0);
+        }
+        if (c + 1 < nchunks) {
+            stage_store(buf ^ 1, sv);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const long long p = p0 + 32 * mt + m0;
+        if (p >= npix) continue;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = 32 * (nt0 + nt) + 8 * q + 4 * hh;
+                float4 v;
+                v.x = acc[nt][mt][4 * q + 0];
+                v.y = acc[nt][mt][4 * q + 1];
+                v.z = acc[nt][mt][4 * q + 2];
+                v.w = acc[nt][mt][4 * q + 3];
+                *reinterpret_cast<float4*>(out + (size_t)p * cout + n) = v;
+            }
+    }
+}
+
 // (n,3,H,W) -> (n,H,W,4) with a zero 4th channel
 __global__ void image_to_nhwc4_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int hw) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -570,7 +697,7 @@ static bool run_conv(const ConvLayer& L, const float* in, int n, int hin, int wi
     return hipGetLastError() == hipSuccess;
 }
 
-bool run_pixel_linear(const ConvLayer& L, const float* in, long long npix, float* out, hipStream_t st) {
+bool run_pixel_linear(const ConvLayer& L, const float* in, long long npix, float* out, hipStream_t st, bool f16x2) {
     if (npix <= 0 || npix > 0x7fffffffll) return false;
     // the tiled GEMM wants K in 32-channel chunks and 256-output blocks (the latent projection: K = 512 | 1792,
     // cout = 512 * view blocks when that is a multiple of 256) and enough pixels to fill tiles; otherwise the generic
@@ -578,8 +705,12 @@ bool run_pixel_linear(const ConvLayer& L, const float* in, long long npix, float
     if (L.cin_p % PL_KC == 0 && L.cout % 256 == 0 && npix >= 2 * PL_PIX) {
         const long long blocks = ((npix + PL_PIX - 1) / PL_PIX) * (L.cout / 256);
         if (blocks <= 0x7fffffffll) {
-            hipLaunchKernelGGL(pixel_linear_kernel, dim3((unsigned)blocks), dim3(64 * PL_NW), 0, st, in, L.w, out, npix,
-                               L.cin_p, L.cout);
+            if (f16x2)
+                hipLaunchKernelGGL(pixel_linear_h2_kernel, dim3((unsigned)blocks), dim3(64 * PL_NW), 0, st, in, L.w, out, npix,
+                                   L.cin_p, L.cout);
+            else
+                hipLaunchKernelGGL(pixel_linear_kernel, dim3((unsigned)blocks), dim3(64 * PL_NW), 0, st, in, L.w, out, npix,
+                                   L.cin_p, L.cout);
             return hipGetLastError() == hipSuccess;
         }
     }

@@ -52,8 +52,8 @@ __device__ __forceinline__ unsigned acc_lane_off(int wave, int lane) {
 }
 
 // acc = (x > 0) ? acc : 0 with x = the stashed relu'd activation of the same element (accumulator layout).
-template <int NT, int MT>
-__device__ __forceinline__ void mask_by(f32x16 (&acc)[NT][MT], const StashRef& x, int wave, int lane) {
+template <int NT, int MT, class Acc>   // Acc = f32x16 (an MFMA accumulator tile) or float[16]
+__device__ __forceinline__ void mask_by(Acc (&acc)[NT][MT], const StashRef& x, int wave, int lane) {
     const unsigned lo = acc_lane_off<NT, MT>(wave, lane);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -72,8 +72,8 @@ __device__ __forceinline__ void mask_by(f32x16 (&acc)[NT][MT], const StashRef& x
         }
 }
 
-template <int NT, int MT>
-__device__ __forceinline__ void acc_load(f32x16 (&acc)[NT][MT], const StashRef& g, int wave, int lane) {
+template <int NT, int MT, class Acc>
+__device__ __forceinline__ void acc_load(Acc (&acc)[NT][MT], const StashRef& g, int wave, int lane) {
     const unsigned lo = acc_lane_off<NT, MT>(wave, lane);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)

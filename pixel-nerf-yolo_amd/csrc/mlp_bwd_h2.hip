@@ -23,8 +23,8 @@ namespace {
 constexpr int BH_LDS = h2::ACT_BYTES + 64;   // activation planes + 8 floats for the tile's max reduction
 
 // acc (scaled domain) -> the two f16 planes of the LDS B operand (TO_LDS) and / or, times inv_sigma, the dY stash (TO_GLOBAL)
-template <bool TO_LDS, bool TO_GLOBAL>
-__device__ __forceinline__ void bh_store(const f32x16 (&acc)[h2::NT][h2::MT], char* planes, const StashRef& g, float inv_sigma,
+template <bool TO_LDS, bool TO_GLOBAL, class Acc>
+__device__ __forceinline__ void bh_store(const Acc (&acc)[h2::NT][h2::MT], char* planes, const StashRef& g, float inv_sigma,
                                          int wave, int lane, float& amax) {
     using namespace h2;
     const int m0 = lane & 31, hh = lane >> 5;
@@ -56,7 +56,10 @@ __device__ __forceinline__ void bh_store(const f32x16 (&acc)[h2::NT][h2::MT], ch
 
 // Reverse of one pre-activation residual block in the scaled domain (block_bwd of mlp_bwd.hip):
 //   dnet = (fc_1^T dh') * [net > 0];   dh = (dh' + (fc_0^T dnet) * [h > 0]) * scale
-__device__ __forceinline__ void bh_block(f32x16 (&dh)[h2::NT][h2::MT], H2Ring& ring, const WStream& ws, const H2Seg& s_fc1t,
+// dh: the gradient of the residual stream as plain floats (it is never an MFMA accumulator inside a block: as f32x16 tiles the
+// compiler kept the 16-register tuples in scratch and re-spilled a whole tuple after every element-wise update)
+typedef float bh_acc[16];
+__device__ __forceinline__ void bh_block(bh_acc (&dh)[h2::NT][h2::MT], H2Ring& ring, const WStream& ws, const H2Seg& s_fc1t,
                                          const H2Seg& s_fc0t, const H2Seg& after, char* planes, const StashRef& x_h,
                                          const StashRef& x_net, const StashRef& dy_dnet, const StashRef& dy_dh, float scale,
                                          float inv_sigma, int wave, int lane, float& amax) {
@@ -176,10 +179,19 @@ __global__ __launch_bounds__(h2::THREADS, 2) void pny_mlp_bwd_h2_kernel(const Bw
             *reinterpret_cast<h4*>(s0 + ROW_BYTES) = p1;
         }
         __syncthreads();
-        f32x16 dh[NT][MT];
-        h2zero<NT, MT>(dh);
-        h2gemm(dh, ring, ws, s_out, nb > 0 ? fc1t(nb - 1) : s_out, planes, lane);
-        mask_by<NT, MT>(dh, x_post(2 * npost), wave, lane);                              // relu(h_top) > 0
+        bh_acc dh[NT][MT];
+        {
+            f32x16 t[NT][MT];
+            h2zero<NT, MT>(t);
+            h2gemm(t, ring, ws, s_out, fc1t(nb - 1), planes, lane);
+            mask_by<NT, MT>(t, x_post(2 * npost), wave, lane);                           // relu(h_top) > 0
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dh[nt][mt][r] = t[nt][mt][r];
+        }
         bh_store<false, true>(dh, nullptr, dy_post(0), inv_sigma, wave, lane, amax);     // dh_top: dY of the last block's fc_1
 
         // ---- post-combine blocks, last to first; the first of them also applies the 1/NS of the cross-view mean
