@@ -244,7 +244,12 @@ int pny_scene_project(pny_scene* s, pny_stream stream);
  * through pny_model_refresh and activations are not checked).  AUTO (default; env PNYOLO_MLP_PRECISION=f32|f16x2 overrides at scene creation) otherwise
  * equals F16X2: every projected launch, whatever its size, so that a ray's result does not depend on the batch it is rendered
  * in.  Launches without projection (training forward, the reference operation order, batches below the projection
- * threshold) always run F32; models with more than 6 residual blocks or combine_layer = 0 always run F32. */
+ * threshold) always run F32; models with more than 6 residual blocks or combine_layer = 0 always run F32.
+ * The setting also selects the arithmetic of the latent projection and of the BACKWARD pass (pny_render_backward,
+ * pny_query_backward, pny_yolo_render_backward, pny_model_flush_weight_grads): scenes not pinned to F32 run the dX chain and
+ * the weight-gradient GEMMs as split-f16 products with power-of-two gradient scaling (csrc/mlp_bwd_h2.hip,
+ * pny_dw_gemm_h2_kernel); a deferred flush runs fp32 when any contributing scene was pinned to F32.  Env
+ * PNYOLO_BWD_PRECISION=f32|f16x2 overrides the backward's choice (read at every call). */
 #define PNY_PRECISION_F32 0
 #define PNY_PRECISION_F16X2 1
 #define PNY_PRECISION_AUTO 2
