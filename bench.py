@@ -145,6 +145,8 @@ def train_main(args):
             dist.init_process_group("nccl", device_id=dev)
     SB, NSV, H, W, RB, KC, KF, KFD = 4, NS, 128, 128, 128, 64, 32, 16
     steps = args.steps if args.steps is not None else 10
+    if args.cudnn_benchmark:   # --train-encoder: let MIOpen search its solvers for the trunk's torch graph (no find-db on a fresh box)
+        torch.backends.cudnn.benchmark = True
     net = make_model(pconf.default_mv()["model"], stop_encoder_grad=not args.train_encoder)
     sd = {}
     sd.update({"mlp_coarse." + k: v for k, v in synth.mlp_state(71).items()})
@@ -152,6 +154,8 @@ def train_main(args):
     sd.update(synth.resnet34_state(74, residual_gain=0.25))
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
     net = net.to(dev).train()
+    if args.precision != "auto":
+        net.set_matrix_precision(args.precision)   # f32: the exact-fp32 kernels for forward and backward
     if not args.train_encoder:
         net.encoder.eval()                                         # train.py:70-73 (--freeze_enc)
         for p_ in net.encoder.parameters():
@@ -216,10 +220,16 @@ def train_main(args):
     # the scenes of the super-batch run on side streams, so per-kernel event times overlap: utilisation is priced
     # against the step's WALL time (a lower bound on the kernels' own efficiency)
     tot_ms, tot_fl = elapsed * 1e3, sum(k_fl)
+    # scenes not pinned to F32 run forward, dX chain and weight gradients as split-f16 products: priced against that ceiling
+    bwd_env = os.environ.get("PNYOLO_BWD_PRECISION", "")
+    h2_train = os.environ.get("PNYOLO_MLP_PRECISION", "") != "f32" and bwd_env != "f32" and args.precision != "f32"
+    train_peak = PEAK_F16X2_TFLOPS if h2_train else PEAK_F32_MFMA_TFLOPS
     out = {
         "metric": "training rays/sec, 64+32 samples/ray, 3-view 128x128 conditioning", "value": world * SB * RB * steps / elapsed,
         "unit": "rays/s", "n_gpus": world, "n_ranks_seen": dist.get_world_size() if dist.is_initialized() else 1, "steps": steps, "warmup": max(args.warmup, 2), "ms_per_step": elapsed / steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (matrix products of forward, dX chain and weight gradients on f16x2 split operands, fp32 accumulate)" if h2_train else "f32",
+        "data": "synthetic",
         "config": {"workload": "train step of the C2 model: SB=4 objects x 3 views 128x128 (%s), 128 rays/object, 64 coarse + "
                                "32 fine (16 depth), MSE coarse+fine, Adam" % (
                                    "ResNet34 trunk TRAINED: torch graph forward / backward + latent-gradient kernel"
@@ -228,7 +238,8 @@ def train_main(args):
                    "parallelism": "dp%d: one super-batch per rank, 1 gradient all-reduce (27 MB fp32) per step" % world},
         "loss_first": float(l0), "loss_last": float(loss),
         "roofline": {"bound": "mfma", "kernel": "MLP kernels of a training step", "achieved": tot_fl / (tot_ms * 1e-3) / 1e12,
-                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                     "peak": train_peak, "unit": "TFLOP/s", "frac": tot_fl / (tot_ms * 1e-3) / 1e12 / train_peak,
+                     "x_fp32_mfma_peak": tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                      "frac_is": "GEMM FLOPs of the step's MLP kernels / step wall time (encode, sampling, composite, "
                                 "optimizer and host time included)", "traffic": None,
                      "kernels": [{"name": n_, "event_ms_per_step_summed_over_concurrent_scenes": m_ / steps,
@@ -254,6 +265,7 @@ def main():
     ap.add_argument("--cpu-rays", type=int, default=None, help="ray subset for the CPU baseline (0 = skip)")
     ap.add_argument("--projection", choices=["auto", "on", "off"], default="auto",
                     help="latent projection mode of the fused MLP (off = the reference's operation order)")
+    ap.add_argument("--cudnn-benchmark", action="store_true", help="--mode train --train-encoder: torch.backends.cudnn.benchmark")
     ap.add_argument("--precision", choices=["auto", "f32", "f16x2"], default="auto",
                     help="matrix arithmetic of projected launches (include/pnyolo.h pny_scene_set_precision)")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the --precision f32 leg of the N=1 line")

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PNY_ABI_VERSION 8
+#define PNY_ABI_VERSION 9
 
 typedef enum pny_status {
     PNY_OK = 0,
@@ -112,6 +112,11 @@ int pny_scene_set_latent(pny_scene* s, const float* latent_dev, int ns, int chan
 /* SpatialEncoder.forward, ResNet-34 trunk, eval-mode batch norm (src/model/encoder.py:139-173).
  * images_dev (ns,3,H,W) in [-1,1].  Leaves the 512-channel latent (H/2 x W/2) in the scene. */
 int pny_scene_encode(pny_scene* s, const float* images_dev, int ns, int height, int width, pny_stream stream);
+/* The same for the n_scenes objects of a super-batch (PixelNeRFNet.encode with images (SB, NS, 3, H, W), src/model/models.py:
+ * 92-151, flattens them into ONE encoder call): images_dev (n_scenes * ns, 3, H, W), scene i owns images [i * ns, (i + 1) * ns).
+ * One pass of the trunk over all of them (41 launches instead of 41 per scene); every scene must belong to the same model,
+ * and all of them are entered on `stream`. */
+int pny_scenes_encode(pny_scene** scenes, int n_scenes, const float* images_dev, int ns, int height, int width, pny_stream stream);
 /* Copies the scene latent out as (ns, L, Hl, Wl) NCHW (test / debugging aid). */
 int pny_scene_get_latent(pny_scene* s, float* latent_dev, pny_stream stream);
 int pny_scene_latent_shape(pny_scene* s, int* ns, int* channels, int* hl, int* wl);

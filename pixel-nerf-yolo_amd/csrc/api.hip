@@ -289,6 +289,8 @@ void pny_model_destroy(pny_model* m) {
     m->packed.release();
     m->repack_jobs.release();
     m->d_absmax.release();
+    m->enc_batch_work.release();
+    m->enc_batch_lat.release();
     for (int w = 0; w < 2; ++w) {
         m->dx_stash[w].release();
         m->ddy_stash[w].release();
@@ -582,6 +584,50 @@ int pny_scene_encode(pny_scene* s, const float* images_dev, int ns, int height, 
     s->wl = wl;
     s->have_latent = true;
     s->zp_valid[0] = s->zp_valid[1] = false;
+    return PNY_OK;
+}
+
+int pny_scenes_encode(pny_scene** scenes, int n_scenes, const float* images_dev, int ns, int height, int width, pny_stream stream) {
+    if (!scenes || n_scenes < 1 || !images_dev) return fail(PNY_ERR_ARG, "pny_scenes_encode: null argument");
+    for (int i = 0; i < n_scenes; ++i)
+        if (!scenes[i] || scenes[i]->m != scenes[0]->m) return fail(PNY_ERR_ARG, "pny_scenes_encode: scenes must share one model");
+    if (n_scenes == 1) return pny_scene_encode(scenes[0], images_dev, ns, height, width, stream);
+    pny_model* m = scenes[0]->m;
+    if (!m->finalized) return fail(PNY_ERR_STATE, "pny_scenes_encode: call pny_model_finalize first");
+    if (!m->has_encoder) return fail(PNY_ERR_STATE, "pny_scenes_encode: no encoder.model.* weights were loaded");
+    if (m->desc.d_latent != 512) return fail(PNY_ERR_ARG, "pny_scenes_encode: ResNet-34 trunk yields 512 channels; model d_latent differs");
+    if (ns < 1 || ns > MAX_VIEWS || height < 32 || width < 32) return fail(PNY_ERR_ARG, "pny_scenes_encode: bad shape");
+    PNY_HIP(hipSetDevice(m->desc.device));
+    int hl = 0, wl = 0;
+    encoder_latent_size(height, width, &hl, &wl);
+    if ((long long)hl * wl * 512 >= (1ll << 31)) return fail(PNY_ERR_ARG, "pny_scenes_encode: latent too large for 32-bit tap offsets");
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    const size_t lat_bytes = (size_t)ns * 512 * hl * wl * sizeof(float);
+    for (int i = 0; i < n_scenes; ++i) {
+        if ((rc = enter_stream(scenes[i], st))) return rc;
+        if ((rc = scenes[i]->latent.reserve(lat_bytes))) return rc;
+    }
+    // ONE pass of the trunk over every scene's images (n_scenes x ns): 41 launches instead of 41 per scene; the images are
+    // independent in an eval-mode trunk, so scene i's latent is the i-th slice of the result
+    const bool pool = m->desc.enc_use_first_pool != 0;
+    const int n_img = n_scenes * ns;
+    if ((rc = m->enc_batch_work.reserve(encoder_workspace_bytes(n_img, height, width, pool)))) return rc;
+    if ((rc = m->enc_batch_lat.reserve(lat_bytes * (size_t)n_scenes))) return rc;
+    std::string err;
+    if (!encoder_forward(m->enc, images_dev, n_img, height, width, pool, m->enc_batch_work.f(), m->enc_batch_lat.f(), st, &err))
+        return fail(PNY_ERR_HIP, "pny_scenes_encode: " + err);
+    for (int i = 0; i < n_scenes; ++i) {
+        pny_scene* s = scenes[i];
+        PNY_HIP(hipMemcpyAsync(s->latent.p, reinterpret_cast<const char*>(m->enc_batch_lat.p) + lat_bytes * (size_t)i, lat_bytes,
+                               hipMemcpyDeviceToDevice, st));
+        s->ns = ns;
+        s->L = 512;
+        s->hl = hl;
+        s->wl = wl;
+        s->have_latent = true;
+        s->zp_valid[0] = s->zp_valid[1] = false;
+    }
     return PNY_OK;
 }
 

@@ -144,6 +144,7 @@ struct pny_model {
     double flush_flops = 0.0;
     int flush_launches = 0;
     EncoderWeights enc;                       // folded conv+bn (encoder.h)
+    DevBuf enc_batch_work, enc_batch_lat;     // pny_scenes_encode: workspace and result of one trunk pass over several scenes
     bool has_encoder = false;
     // lin_z[0..nvb) of the coarse / fine MLP stacked into one (nvb*512 x d_latent) pixel-wise map
     ConvLayer zproj[2];

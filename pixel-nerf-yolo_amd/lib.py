@@ -68,6 +68,7 @@ SIGNATURES = {
                                         C.c_int, C.c_int]),
     "pny_scene_set_latent": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pny_scene_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pny_scenes_encode": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pny_scene_get_latent": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pny_scene_latent_shape": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_int)] * 4),
     "pny_gen_rays": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, C.c_float, C.c_float,
@@ -117,7 +118,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 8
+ABI_VERSION = 9
 PROJECTION = {"off": 0, "on": 1, "auto": 2}
 PRECISION = {"f32": 0, "f16x2": 1, "auto": 2}
 

@@ -493,19 +493,22 @@ class PixelNeRFNet(nn.Module):
         return grads
 
     def fork_streams(self, n):
-        """n stream contexts for n independent scenes: side streams ordered behind the current stream (None = stay on the
-        current stream when there is a single scene or PNYOLO_SCENE_STREAMS=0)."""
+        """n stream contexts for n independent scenes: the current stream for the first scene (None) and n - 1 side streams
+        ordered behind it for the others (all None when there is a single scene or PNYOLO_SCENE_STREAMS=0).  The current
+        stream takes part because the runtime maps streams onto FOUR hardware queues, one of which is the current stream's:
+        with four side streams two scenes of the reference's default super-batch (SB = 4) shared a queue and ran one after
+        the other while two queues idled (kernel trace of a training step)."""
         import os
         if n <= 1 or os.environ.get("PNYOLO_SCENE_STREAMS", "1") == "0":
             return [None] * n
         dev = self._device()
         pool = getattr(self, "_side_streams", None)
-        if pool is None or len(pool) < n or pool[0].device != dev:
-            pool = self._side_streams = [torch.cuda.Stream(dev) for _ in range(n)]
+        if pool is None or len(pool) < n - 1 or pool[0].device != dev:
+            pool = self._side_streams = [torch.cuda.Stream(dev) for _ in range(n - 1)]
         main = torch.cuda.current_stream(dev)
-        for st in pool[:n]:
+        for st in pool[:n - 1]:
             st.wait_stream(main)
-        return pool[:n]
+        return [None] + pool[:n - 1]
 
     def join_streams(self, streams):
         main = torch.cuda.current_stream(self._device())
@@ -584,7 +587,13 @@ class PixelNeRFNet(nn.Module):
                 self._sync()
             images = images.detach().to(dev, torch.float32).contiguous()
         scenes = [self._scene(sb) for sb in range(SB)]
-        streams = self.fork_streams(SB)       # the scenes' trunks are independent: one side stream each
+        # the library's trunk over a super-batch: ONE pass over all SB * NS images (as the reference's encode flattens them),
+        # cameras per scene below
+        batch_encode = latent is None and SB > 1
+        if batch_encode:
+            arr = (C.c_void_p * SB)(*[s_ for s_ in scenes])
+            check(L.pny_scenes_encode(arr, SB, ptr(images), NS, H, W, stream_of(dev)))
+        streams = [None] * SB if batch_encode else self.fork_streams(SB)   # independent scenes: one stream each
         for sb in range(SB):
           with torch.cuda.stream(streams[sb]):
             s = scenes[sb]
@@ -604,7 +613,7 @@ class PixelNeRFNet(nn.Module):
             if latent is not None:
                 lat = latent[sb * NS:(sb + 1) * NS]
                 check(L.pny_scene_set_latent(s, ptr(lat), NS, lat.shape[1], lat.shape[2], lat.shape[3], st))
-            else:
+            elif not batch_encode:
                 img = images[sb * NS:(sb + 1) * NS]
                 check(L.pny_scene_encode(s, ptr(img), NS, H, W, st))
         self.join_streams(streams)

@@ -288,6 +288,30 @@ def test_encoder_golden(golden):
     assert maxabs(lat, g["latent"]) < 2e-5 * scale  # random-weight trunk: activations reach O(100)
 
 
+def test_super_batch_encode_is_one_trunk_pass_with_per_scene_results(golden):
+    """encode() of a super-batch runs ONE pass of the trunk over all SB * NS images (pny_scenes_encode): scene 0's latent is
+    still the reference's (golden), and every scene's latent equals what its own single-scene encode gives."""
+    g = golden("encoder")
+    net = make_model(pconf.default_mv()["model"]).eval()
+    sd = synth.resnet34_state(45, prefix="encoder.model.")
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    net = net.to(DEV)
+    ns, H, W = int(g["NS"]), int(g["H"]), int(g["W"])
+    SB = 3
+    imgs = torch.from_numpy(np.stack([synth.images(46 + i, ns, H, W) for i in range(SB)]))
+    src, _ = synth.scene_cameras(ns)
+    poses = torch.from_numpy(np.stack([src] * SB))
+    net.encode(imgs, poses, torch.tensor(60.0))
+    lats = [net.latent(i).clone() for i in range(SB)]
+    scale = float(np.abs(g["latent"]).max())
+    assert maxabs(lats[0], g["latent"]) < 2e-5 * scale
+    for i in range(SB):
+        net.encode(imgs[i:i + 1], poses[i:i + 1], torch.tensor(60.0))
+        single = net.latent(0)
+        assert maxabs(lats[i], single) < 2e-6 * scale, i   # (the split-K variant of a layer may differ with the image count)
+    assert maxabs(lats[1], lats[0]) > 1e-2 * scale           # different images, different latents
+
+
 # --------------------------------------------------------------------------- oracle, ragged sizes
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 257])
 def test_query_ragged_vs_oracle(golden, n, projection):
