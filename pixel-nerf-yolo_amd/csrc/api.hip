@@ -40,14 +40,29 @@ int enter_stream(pny_scene* s, hipStream_t st) {
             s->order_ev = nullptr;
             return hip_fail(hipGetLastError(), "hipEventCreate(stream order)");
         }
-        if (hipEventRecord(s->order_ev, s->last_stream) == hipSuccess) {
+        if (s->order_ev_valid) {   // recorded right behind the previous call's work (mark_stream_point)
+            PNY_HIP(hipStreamWaitEvent(st, s->order_ev, 0));
+        } else if (hipEventRecord(s->order_ev, s->last_stream) == hipSuccess) {
             PNY_HIP(hipStreamWaitEvent(st, s->order_ev, 0));
         } else {
             (void)hipGetLastError();  // the previous stream no longer exists: its work has drained
         }
     }
+    s->order_ev_valid = false;   // the call that enters enqueues new work
     s->last_stream = st;
     s->has_last_stream = true;
+    return 0;
+}
+// Records the scene's order event NOW, behind the work just enqueued on its stream: a later call on another stream then waits
+// for exactly this point and not for whatever else the first stream has been given in between (pny_scenes_encode: the scenes
+// of a super-batch are encoded on one stream and rendered on one stream each).
+int mark_stream_point(pny_scene* s, hipStream_t st) {
+    if (!s->order_ev && hipEventCreateWithFlags(&s->order_ev, hipEventDisableTiming) != hipSuccess) {
+        s->order_ev = nullptr;
+        return hip_fail(hipGetLastError(), "hipEventCreate(stream order)");
+    }
+    PNY_HIP(hipEventRecord(s->order_ev, st));
+    s->order_ev_valid = true;
     return 0;
 }
 }  // namespace pny
@@ -628,6 +643,8 @@ int pny_scenes_encode(pny_scene** scenes, int n_scenes, const float* images_dev,
         s->have_latent = true;
         s->zp_valid[0] = s->zp_valid[1] = false;
     }
+    for (int i = 0; i < n_scenes; ++i)
+        if ((rc = mark_stream_point(scenes[i], st))) return rc;
     return PNY_OK;
 }
 

@@ -199,6 +199,7 @@ struct pny_scene {
     hipStream_t last_stream = nullptr;
     bool has_last_stream = false;
     hipEvent_t order_ev = nullptr;
+    bool order_ev_valid = false;             // order_ev was recorded behind the last call's work (api.hip mark_stream_point)
 };
 
 

@@ -481,15 +481,23 @@ class PixelNeRFNet(nn.Module):
 
     def bind_mlp_grads(self):
         """Fresh zeroed gradient buffers for trainable_mlp_parameters(), bound to the native model by name
-        (pny_model_bind_grad); returns them in the same order."""
+        (pny_model_bind_grad); returns them in the same order.  The buffers are views of ONE flat allocation (one fill
+        instead of one per tensor); only the flat tensor is kept alive here, so that autograd's AccumulateGrad can adopt the
+        returned views as `.grad` instead of cloning each of them."""
         self._sync()
         L = _lib.load()
+        named = list(self.trainable_mlp_parameters())
+        offs, total = [], 0
+        for _, p in named:
+            offs.append(total)
+            total += (p.numel() + 63) // 64 * 64          # 256-byte aligned starts (the reduction writes float4 rows)
+        flat = torch.zeros(max(total, 1), device=self._device(), dtype=torch.float32)
         grads = []
-        for name, p in self.trainable_mlp_parameters():
-            g = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.contiguous_format)
+        for (name, p), o in zip(named, offs):
+            g = flat[o:o + p.numel()].view(p.shape)
             check(L.pny_model_bind_grad(self._h_model, name.encode(), ptr(g)))
             grads.append(g)
-        self._bound_grads = grads   # keep the buffers alive while they are bound
+        self._bound_grads = flat   # keeps the memory alive while it is bound
         return grads
 
     def fork_streams(self, n):
