@@ -145,8 +145,6 @@ def train_main(args):
             dist.init_process_group("nccl", device_id=dev)
     SB, NSV, H, W, RB, KC, KF, KFD = 4, NS, 128, 128, 128, 64, 32, 16
     steps = args.steps if args.steps is not None else 10
-    if args.cudnn_benchmark:   # --train-encoder: let MIOpen search its solvers for the trunk's torch graph (no find-db on a fresh box)
-        torch.backends.cudnn.benchmark = True
     net = make_model(pconf.default_mv()["model"], stop_encoder_grad=not args.train_encoder)
     sd = {}
     sd.update({"mlp_coarse." + k: v for k, v in synth.mlp_state(71).items()})
@@ -265,7 +263,6 @@ def main():
     ap.add_argument("--cpu-rays", type=int, default=None, help="ray subset for the CPU baseline (0 = skip)")
     ap.add_argument("--projection", choices=["auto", "on", "off"], default="auto",
                     help="latent projection mode of the fused MLP (off = the reference's operation order)")
-    ap.add_argument("--cudnn-benchmark", action="store_true", help="--mode train --train-encoder: torch.backends.cudnn.benchmark")
     ap.add_argument("--precision", choices=["auto", "f32", "f16x2"], default="auto",
                     help="matrix arithmetic of projected launches (include/pnyolo.h pny_scene_set_precision)")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the --precision f32 leg of the N=1 line")
