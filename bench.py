@@ -194,6 +194,11 @@ def train_main(args):
     fence()
     net.enable_kernel_timing(True)
     k_ms, k_fl = [0.0] * 4, [0.0] * 4
+    prof = None
+    if os.environ.get("PNYOLO_BENCH_HOST_PROFILE"):   # diagnostic: cProfile of the timed loop on stderr
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     for i in range(steps):
         loss = step(100 + i)
@@ -208,6 +213,10 @@ def train_main(args):
         k_ms[3] += fm
     fence()
     elapsed = time.perf_counter() - t0
+    if prof is not None:
+        import pstats
+        prof.disable()
+        pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(28)
     if world > 1:
         tmax = torch.tensor([elapsed], device="cpu" if args.rehearse_one_gpu else dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
