@@ -476,28 +476,6 @@ __global__ __launch_bounds__(512, 2) void pny_dw_gemm_h2_kernel(const DwJob* __r
                     if (FULL || (live_a[i] && live_x[j])) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[i], x2[j], acc[i][j], 0, 0, 0);
         }
     };
-#ifdef PNY_DWH_STAGE_LAST
-    // experiment: branch-free body -- the MFMAs of half h, then (in program order) the staging of half h + 1 and the loads of
-    // half h + 2 (clamped: a redundant re-load at the end), interleaved by scheduling groups; the last half behind the loop
-    for (int h = 0; h + 1 < n_half; ++h) {
-        const int cb = h & 1;
-        mm(cb);
-        stage(cb ^ 1);
-        fetch(h + 2 < n_half ? h + 2 : n_half - 1);
-        if (FULL) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);    // 6 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);    // 3 LDS reads
-                __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);   // 16 VALU
-                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);    // 1 LDS write
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // 1 global load
-            }
-        }
-        __syncthreads();
-    }
-    if (n_half > 0) mm((n_half - 1) & 1);
-#else
     for (int h = 0; h < n_half; ++h) {
         const int cb = h & 1;
         if (h + 1 < n_half) {
@@ -507,7 +485,6 @@ __global__ __launch_bounds__(512, 2) void pny_dw_gemm_h2_kernel(const DwJob* __r
         mm(cb);
         __syncthreads();
     }
-#endif
     float* P = partial + it.part_off;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
