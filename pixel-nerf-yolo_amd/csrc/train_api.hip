@@ -166,7 +166,7 @@ void build_items(TrainPlan& p, int n_tiles, int cus, std::vector<DwItem>& items,
 // Matrix arithmetic of the backward's GEMMs (dX chain and weight gradients): the scene's precision setting (F32 pins the fp32
 // MFMA; anything else = split f16: mlp_bwd_h2.hip pny_mlp_bwd_h2_kernel, mlp_bwd.hip pny_dw_gemm_h2_kernel); env
 // PNYOLO_BWD_PRECISION=f32|f16x2 overrides (read at every call: tests vary it).
-bool dw_use_h2(const pny_scene* s) {
+bool bwd_use_h2(const pny_scene* s) {
     if (const char* e = getenv("PNYOLO_BWD_PRECISION")) {
         if (!strcmp(e, "f32")) return false;
         if (!strcmp(e, "f16x2")) return true;
@@ -291,7 +291,7 @@ int mlp_backward(pny_scene* s, int mode, const float* xyz, const float* dirs, co
     if ((rc = s->out_tmp.reserve((size_t)chunk_pts * d.d_out * sizeof(float)))) return rc;
     // running max |dY| for the split-f16 weight-gradient GEMM: per model and MLP in deferred mode (every scene's chain adds
     // to it, zeroed again by the flush), per scene otherwise (zeroed in front of every chunk's chain)
-    const bool dw_h2 = dw_use_h2(s);
+    const bool dw_h2 = bwd_use_h2(s);
     unsigned* absmax = nullptr;
     if (defer || have_x) {
         if (!dw_h2) m->defer_dw_f32 = true;
