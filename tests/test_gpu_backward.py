@@ -25,9 +25,7 @@ RTOL = 1e-4
 # tests that run under both backward arithmetics; every other test runs the split-f16 backward (the default of scenes that are
 # not pinned to F32) only
 BOTH_BACKWARD_ARITHMETICS = {"test_query_backward_vs_oracle_autograd", "test_render_backward_vs_oracle",
-                             "test_training_gradients_reference_golden", "test_yolo_render_backward_vs_oracle",
-                             "test_render_backward_super_batch", "test_backward_recompute_in_chunks",
-                             "test_weight_gradients_f16x2_any_gradient_scale", "test_device_refresh_equals_full_reupload"}
+                             "test_training_gradients_reference_golden", "test_weight_gradients_f16x2_any_gradient_scale"}
 
 
 @pytest.fixture(autouse=True, params=["dw_f32", "dw_f16x2"])
