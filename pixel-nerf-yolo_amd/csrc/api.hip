@@ -938,12 +938,20 @@ static int run_mlp(pny_scene* s, int mode, const float* xyz, const float* dirs, 
     const bool use_h2 = a.zp && mlp_h2_supports(d.n_blocks, d.combine_layer) && s->precision != PNY_PRECISION_F32 &&
                         (s->m->f16_weights_ok || s->precision == PNY_PRECISION_F16X2);
     if (use_h2) variant = MLP_8x64;
-    const int tm = mlp_tile_samples(variant);
+    // Split shape of the f16x2 kernel (mlp_h2s.hip: 32-sample tiles, 4-wave workgroups, two per CU): the same arithmetic per
+    // sample, bit for bit.  Measured (profiles/r02zk_split_sweep.log): a launch that gives every CU at most ONE 32-sample tile
+    // takes 0.40-0.43 ms against 0.47-0.51 ms on 64-sample tiles; as soon as two workgroups share a CU the doubled weight
+    // stream per sample costs more than the overlap of their phases returns (full C2 frame: 61.7 vs 39.9 ms per launch).
+    // So: launches of at most 32 x CUs points.  PNYOLO_H2_SPLIT=0|1 overrides.
+    bool use_h2s = use_h2 && n_points <= 32ll * mlp_max_grid(MLP_8x64);
+    if (use_h2)
+        if (const char* e = getenv("PNYOLO_H2_SPLIT")) use_h2s = atoi(e) != 0;
+    const int tm = use_h2s ? 32 : mlp_tile_samples(variant);
     const long long tiles = (n_points + tm - 1) / tm;
     if (tiles > 0x7fffffffll) return fail(PNY_ERR_ARG, "too many points for one launch");
     a.n_tiles = (int)tiles;
     a.idx32 = (tiles * tm) < 0xffffffffll;
-    int grid = mlp_max_grid(variant);
+    int grid = use_h2s ? 2 * mlp_max_grid(MLP_8x64) : mlp_max_grid(variant);
     if (const char* e = getenv("PNYOLO_GRID")) {  // diagnostic: fewer resident workgroups
         const int g = atoi(e);
         if (g > 0 && g < grid) grid = g;
@@ -957,7 +965,9 @@ static int run_mlp(pny_scene* s, int mode, const float* xyz, const float* dirs, 
         }
         PNY_HIP(hipEventRecord(s->ev[s->ev_used], st));
     }
-    if (use_h2)
+    if (use_h2s)
+        launch_mlp_h2s(a, grid, st);
+    else if (use_h2)
         launch_mlp_h2(a, grid, st);
     else
         launch_mlp(a, variant, grid, st);

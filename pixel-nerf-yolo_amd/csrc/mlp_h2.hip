@@ -36,6 +36,15 @@
 
 #include "mlp_h2_core.h"
 
+// The same source is the SPLIT shape's translation unit (mlp_h2s.hip: -DPNY_H2_SPLIT with PNY_H2_NT = 4, PNY_H2_MT = 1;
+// mlp_h2_core.h): 4 waves, 32-sample tiles, 65 KiB of LDS and two workgroups per CU; render only (no STASH instantiation: the
+// backward's stash is laid out on 64-sample tiles), biases read from global memory instead of an LDS table.
+#ifdef PNY_H2_SPLIT
+#define PNY_H2_KERNEL pny_mlp_h2s_kernel
+#else
+#define PNY_H2_KERNEL pny_mlp_h2_kernel
+#endif
+
 namespace pny {
 
 // Diagnostic build only (-DPNY_H2_STAMP): s_memtime brackets around the phases of a tile, summed per wave and printed by
@@ -274,7 +283,7 @@ __device__ __forceinline__ void h2prologue(const MlpArgs& a, int v, long long ti
 // raw latent per view: the weight gradient of lin_z needs it, the forward itself only the projected maps), relu(h_in) and
 // relu(net) of every block, relu(h_top) -- in the layout the fp32 STASH kernel of mlp.hip writes.
 template <bool STASH>
-__global__ __launch_bounds__(h2::THREADS, 2) void pny_mlp_h2_kernel(const MlpArgs a) {
+__global__ __launch_bounds__(h2::THREADS, 2) void PNY_H2_KERNEL(const MlpArgs a) {
     using namespace h2;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     char* planes = smem_raw;
@@ -297,8 +306,14 @@ __global__ __launch_bounds__(h2::THREADS, 2) void pny_mlp_h2_kernel(const MlpArg
 #endif
     // bias applied at the entry of block b (b = n_blocks: before lin_out): b_in, or the previous block's b_fc1 -- the host
     // (api.hip pack_mlp) has folded the block's lin_z bias into either
-    auto entry_bias = [&](int b) { return bias_tab + (b == 0 ? 0 : 2 * b) * HID; };
-    auto fc0_bias = [&](int b) { return bias_tab + (1 + 2 * b) * HID; };
+    auto entry_bias = [&](int b) -> const float* {
+        if constexpr (LDS_BIAS) return bias_tab + (b == 0 ? 0 : 2 * b) * HID;
+        return b == 0 ? a.w.b_in : a.w.b_fc1[b - 1];   // (folded with the block's lin_z bias by api.hip pack_mlp)
+    };
+    auto fc0_bias = [&](int b) -> const float* {
+        if constexpr (LDS_BIAS) return bias_tab + (1 + 2 * b) * HID;
+        return a.w.b_fc0[b];
+    };
     H2Ring ring;
     h2ring_fill(ring, ws, s_in);
 #ifdef PNY_H2_STAMP
@@ -306,10 +321,12 @@ __global__ __launch_bounds__(h2::THREADS, 2) void pny_mlp_h2_kernel(const MlpArg
     for (int i = 0; i < HS_N; ++i) hs_acc[i] = 0;
     const unsigned long long hs_start = h2now();
 #endif
-    for (int i = tid; i < (1 + 2 * nb) * HID; i += THREADS) {
-        const int vec = i / HID, f = i % HID;
-        const float* src = vec == 0 ? a.w.b_in : ((vec & 1) ? a.w.b_fc0[(vec - 1) >> 1] : a.w.b_fc1[(vec - 2) >> 1]);
-        bias_tab[i] = src[f];
+    if constexpr (LDS_BIAS) {
+        for (int i = tid; i < (1 + 2 * nb) * HID; i += THREADS) {
+            const int vec = i / HID, f = i % HID;
+            const float* src = vec == 0 ? a.w.b_in : ((vec & 1) ? a.w.b_fc0[(vec - 1) >> 1] : a.w.b_fc1[(vec - 2) >> 1]);
+            bias_tab[i] = src[f];
+        }
     }
 
     const bool xcd_order = (gridDim.x & 7) == 0;   // see mlp.hip
@@ -511,11 +528,13 @@ __global__ __launch_bounds__(h2::THREADS, 2) void pny_mlp_h2_kernel(const MlpArg
 #ifdef PNY_H2_STAMP
     hs_acc[HS_TOTAL] = h2now() - hs_start;
     if (lane == 0)
-        for (int i = 0; i < HS_N; ++i) g_h2_stamp_buf[((size_t)blockIdx.x * 8 + wave) * HS_N + i] = hs_acc[i];
+        for (int i = 0; i < HS_N; ++i) g_h2_stamp_buf[((size_t)blockIdx.x * (THREADS / 64) + wave) * HS_N + i] = hs_acc[i];
 #endif
 }
 
+#ifndef PNY_H2_SPLIT
 bool mlp_h2_supports(int n_blocks, int combine_layer) { return n_blocks <= h2::MAX_NB && combine_layer >= 1; }
+#endif
 
 template <bool STASH>
 static void launch_mlp_h2_t(const MlpArgs& a, int grid, hipStream_t st) {
@@ -525,20 +544,21 @@ static void launch_mlp_h2_t(const MlpArgs& a, int grid, hipStream_t st) {
     dev_ &= 63;
     const int extra = STASH ? h2::TAP_BYTES : 0;   // second tap table
     if (!attr_set[dev_]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pny_mlp_h2_kernel<STASH>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(PNY_H2_KERNEL<STASH>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   h2::lds_bytes(h2::MAX_NB) + extra);
         attr_set[dev_] = true;
     }
 #ifdef PNY_H2_STAMP
     static unsigned long long* dbuf = nullptr;
-    const size_t nst = (size_t)grid * 8 * HS_N;
+    constexpr int NWV = h2::THREADS / 64;
+    const size_t nst = (size_t)grid * NWV * HS_N;
     if (!dbuf) {
         (void)hipMalloc((void**)&dbuf, (size_t)1024 * 8 * HS_N * sizeof(unsigned long long));
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_h2_stamp_buf), &dbuf, sizeof(dbuf));
     }
     (void)hipMemsetAsync(dbuf, 0, nst * sizeof(unsigned long long), st);
 #endif
-    hipLaunchKernelGGL(pny_mlp_h2_kernel<STASH>, dim3(grid), dim3(h2::THREADS), h2::lds_bytes(a.n_blocks) + extra, st, a);
+    hipLaunchKernelGGL(PNY_H2_KERNEL<STASH>, dim3(grid), dim3(h2::THREADS), h2::lds_bytes(a.n_blocks) + extra, st, a);
 #ifdef PNY_H2_STAMP
     {
         std::vector<unsigned long long> hst(nst);
@@ -547,15 +567,20 @@ static void launch_mlp_h2_t(const MlpArgs& a, int grid, hipStream_t st) {
         double sum[HS_N] = {0};
         for (size_t i = 0; i < nst; ++i) sum[i % HS_N] += (double)hst[i];
         static const char* names[HS_N] = {"total", "gemm", "gather-barrier-wait", "gather", "epilogue-barrier-wait", "epilogue", "prologue", "lin_out", "slab"};
-        fprintf(stderr, "[h2 stamp%s] tiles=%d grid=%d:", STASH ? ", stash" : "", a.n_tiles, grid);
+        fprintf(stderr, "[h2 stamp%s, %d x %d] tiles=%d grid=%d:", STASH ? ", stash" : "", h2::NT, h2::MT, a.n_tiles, grid);
         for (int i = 0; i < HS_N; ++i) fprintf(stderr, " %s=%.1f%%", names[i], 100.0 * sum[i] / sum[0]);
-        fprintf(stderr, " (mean wave cycles %.4g)\n", sum[0] / ((double)grid * 8));
+        fprintf(stderr, " (mean wave cycles %.4g)\n", sum[0] / ((double)grid * NWV));
     }
 #endif
 }
 
+#ifdef PNY_H2_SPLIT
+// 32-sample tiles, two workgroups per CU: a.n_tiles counts 32-sample tiles, grid <= 2 x CUs
+void launch_mlp_h2s(const MlpArgs& a, int grid, hipStream_t st) { launch_mlp_h2_t<false>(a, grid, st); }
+#else
 void launch_mlp_h2(const MlpArgs& a, int grid, hipStream_t st) { launch_mlp_h2_t<false>(a, grid, st); }
 // training forward: a.stash_x / a.lay set, a.zp AND a.latent valid (152 + 2 KiB of LDS for 5 blocks)
 void launch_mlp_h2_stash(const MlpArgs& a, int grid, hipStream_t st) { launch_mlp_h2_t<true>(a, grid, st); }
+#endif
 
 }  // namespace pny

@@ -14,13 +14,25 @@ namespace h2 {
 #ifndef PNY_H2_WD
 #define PNY_H2_WD 2  // measured: 4 is 7 % faster inside the GEMMs, but its 32 more ring registers spill in the gather phase (-17 % overall)
 #endif
-constexpr int NT = 2, MT = 2, TM = 64, THREADS = 512, WD = PNY_H2_WD;  // WD = ring depth in 16-k steps
-constexpr int ROW_BYTES = TM * 16;          // one plane of one row (8 features x 64 samples x f16)
-constexpr int ACT_BYTES = 64 * 2 * ROW_BYTES;  // activation buffer: [row = feature / 8][plane][sample] x 16 bytes = 128 KiB
+// Tile shape of the translation unit (a wave owns NT n-tiles of 32 features x MT m-tiles of 32 samples; NT * MT = 4):
+//   2 x 2 (default): 8 waves, 64-sample tiles, one workgroup per CU (152 KiB of LDS) -- mlp_h2.hip, mlp_bwd_h2.hip;
+//   4 x 1 (mlp_h2s.hip, -DPNY_H2_NT=4 -DPNY_H2_MT=1): 4 waves, 32-sample tiles, 65 KiB of LDS, TWO workgroups per CU whose
+//   phases interleave (one's gather / epilogue under the other's GEMM) at twice the weight stream per sample.
+#ifndef PNY_H2_NT
+#define PNY_H2_NT 2
+#endif
+#ifndef PNY_H2_MT
+#define PNY_H2_MT 2
+#endif
+constexpr int NT = PNY_H2_NT, MT = PNY_H2_MT, TM = 32 * MT, THREADS = 64 * (16 / NT), WD = PNY_H2_WD;  // WD = ring depth in 16-k steps
+static_assert(NT * MT == 4 && 16 % NT == 0, "tile shape");
+constexpr bool LDS_BIAS = (NT == 2 && MT == 2);   // the bias table lives in LDS (22 KiB); the split shape reads biases from global
+constexpr int ROW_BYTES = TM * 16;          // one plane of one row (8 features x TM samples x f16)
+constexpr int ACT_BYTES = 64 * 2 * ROW_BYTES;  // activation buffer: [row = feature / 8][plane][sample] x 16 bytes (128 KiB at TM = 64)
 constexpr int TAP_BYTES = 32 * TM;             // tap table
-constexpr int MAX_NB = 6;                      // bias table: (1 + 2 n_blocks) x 512 floats must fit the 160 KiB with the rest
-__host__ __device__ constexpr int lds_bytes(int n_blocks) { return ACT_BYTES + TAP_BYTES + (1 + 2 * n_blocks) * HID * 4; }
-using C = Cfg<2, 2>;
+constexpr int MAX_NB = LDS_BIAS ? 6 : MAX_BLOCKS;   // bias table: (1 + 2 n_blocks) x 512 floats must fit the 160 KiB with the rest
+__host__ __device__ constexpr int lds_bytes(int n_blocks) { return ACT_BYTES + TAP_BYTES + (LDS_BIAS ? (1 + 2 * n_blocks) * HID * 4 : 0); }
+using C = Cfg<NT, MT>;
 }  // namespace h2
 
 struct H2Seg {
@@ -106,13 +118,13 @@ __device__ __forceinline__ void h2gemm(f32x16 (&acc)[h2::NT][h2::MT], H2Ring& r,
 #pragma unroll
             for (int i = 0; i < NT * MT; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, NT * 2 / (NT * MT), 0);   // the step's NT x 2 weight loads
                 __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);
             }
 #endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int p = 0; p < 2; ++p) B[(d + 1) & 1][0][p] = *reinterpret_cast<const h8*>(bj + p * ROW_BYTES);
+            for (int p = 0; p < 2; ++p) B[(d + 1) & 1][0][p] = *reinterpret_cast<const h8*>(bj + p * ROW_BYTES);   // (m-tile 0)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -127,8 +139,10 @@ __device__ __forceinline__ void h2gemm(f32x16 (&acc)[h2::NT][h2::MT], H2Ring& r,
             }
 #endif
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (MT > 1) {
 #pragma unroll
-            for (int p = 0; p < 2; ++p) B[(d + 1) & 1][1][p] = *reinterpret_cast<const h8*>(bj + p * ROW_BYTES + 32 * 16);
+                for (int p = 0; p < 2; ++p) B[(d + 1) & 1][MT - 1][p] = *reinterpret_cast<const h8*>(bj + p * ROW_BYTES + 32 * 16);
+            }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -138,7 +152,7 @@ __device__ __forceinline__ void h2gemm(f32x16 (&acc)[h2::NT][h2::MT], H2Ring& r,
 #pragma unroll
             for (int i = 0; i < NT * MT; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (i < 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (MT > 1 && i < 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);
             }
 #endif

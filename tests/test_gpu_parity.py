@@ -44,6 +44,9 @@ def projection(request, monkeypatch):
     mode, _, prec = request.param.partition("+")
     monkeypatch.setenv("PNYOLO_PROJECTION", mode)
     monkeypatch.setenv("PNYOLO_MLP_PRECISION", prec or "f32")
+    # the f16x2 leg runs the 64-sample shape of the kernel (the one a full frame uses) whatever the launch size; the 32-sample
+    # shape that small launches pick by themselves is held to it bit for bit (test_f16x2_split_shape_is_bit_identical)
+    monkeypatch.setenv("PNYOLO_H2_SPLIT", "0")
     return mode
 
 
@@ -286,6 +289,27 @@ def test_encoder_golden(golden):
     assert lat.shape == g["latent"].shape
     scale = float(np.abs(g["latent"]).max())
     assert maxabs(lat, g["latent"]) < 2e-5 * scale  # random-weight trunk: activations reach O(100)
+
+
+@pytest.mark.parametrize("n", [40, 4096, 9000])
+def test_f16x2_split_shape_is_bit_identical(golden, n, monkeypatch):
+    """The f16x2 kernel has two tile shapes (csrc/mlp_h2.hip: 8 waves x 64 samples; csrc/mlp_h2s.hip: 4 waves x 32 samples, picked
+    for launches of at most 32 x CUs points): the same products in the same order for every sample, so the shape -- and with it
+    the size of the batch a point is evaluated in -- never shows in a result."""
+    g = golden("nerf_c2")
+    monkeypatch.setenv("PNYOLO_PROJECTION", "on")
+    monkeypatch.setenv("PNYOLO_MLP_PRECISION", "f16x2")
+    rs = np.random.RandomState(n)
+    xyz = rs.uniform(-0.5, 0.5, size=(n, 3)).astype(np.float32)
+    vd = rs.standard_normal((n, 3)).astype(np.float32)
+    outs = []
+    for split in ("0", "1"):
+        monkeypatch.setenv("PNYOLO_H2_SPLIT", split)
+        net = nerf_net(g, 7)
+        with torch.no_grad():
+            outs.append(net(dt(xyz)[None], coarse=True, viewdirs=dt(vd)[None])[0].clone())
+        assert net.last_launch_f16x2()
+    assert torch.equal(outs[0], outs[1])
 
 
 def test_super_batch_encode_is_one_trunk_pass_with_per_scene_results(golden):
