@@ -87,6 +87,24 @@ def render_frame_sharded(render_fn, pose, width, height, focal, z_near, z_far, c
     return full[:, :3].reshape(height, width, 3), full[:, 3].reshape(height, width)
 
 
+def _common_flat_span(params):
+    """One fp32 tensor over the storage range that holds every ``p.grad`` of ``params`` when all of them are contiguous fp32
+    views of ONE storage (and every parameter has a gradient); else None."""
+    grads = [p.grad for p in params]
+    if any(g is None or g.dtype != torch.float32 or not g.is_contiguous() for g in grads):
+        return None
+    st = grads[0].untyped_storage()
+    if any(g.untyped_storage().data_ptr() != st.data_ptr() for g in grads[1:]):
+        return None
+    ivs = sorted((g.storage_offset(), g.storage_offset() + g.numel()) for g in grads)
+    if any(a[1] > b[0] for a, b in zip(ivs, ivs[1:])):   # overlapping views: not a partition of the range
+        return None
+    lo, hi = ivs[0][0], ivs[-1][1]
+    if (hi - lo) > 2 * sum(g.numel() for g in grads):       # mostly foreign memory between the views: not worth it
+        return None
+    return torch.empty(0, dtype=torch.float32, device=grads[0].device).set_(st, lo, (hi - lo,))
+
+
 def allreduce_gradients(params, group=None, bucket_bytes=64 << 20, average=True):
     """Data-parallel training over ranks that each ran ``loss.backward()`` on their own super-batch (the reference trains on
     one GPU; its DataParallel splits rays, not objects -- SURVEY.md 2.3): sum the ``.grad`` of ``params`` over the ranks and
@@ -98,6 +116,30 @@ def allreduce_gradients(params, group=None, bucket_bytes=64 << 20, average=True)
     params = [p for p in params if p.requires_grad]
     if world == 1 or not params:
         return 0
+    # The renderer's backward hands out the MLP gradients as views of ONE flat fp32 allocation (PixelNeRFNet.bind_mlp_grads): when
+    # every gradient of `params` lives in one storage, reduce that storage's covering range in place -- one collective, no
+    # flatten / scatter copies (the alignment gaps between the views are zeros on every rank).
+    span = _common_flat_span(params)
+    if span is not None and span.numel() * 4 > bucket_bytes:
+        span = None
+    # every rank must take the same path: agree on "all of us have a flat span of the same length" (one 2-word collective)
+    n_span = span.numel() if span is not None else 0
+    on_host = dist.get_backend(group) == "gloo"
+    ref_dev = "cpu" if on_host else next(p.device for p in params)
+    vote = torch.tensor([n_span, -n_span], dtype=torch.int64, device=ref_dev)
+    dist.all_reduce(vote, op=dist.ReduceOp.MIN, group=group)
+    if not (n_span > 0 and int(vote[0]) == n_span and int(vote[1]) == -n_span):
+        span = None
+    if span is not None:
+        if span.is_cuda and dist.get_backend(group) == "gloo":   # rehearsals on one GPU: gloo moves host memory
+            host = span.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            span.copy_(host)
+        else:
+            dist.all_reduce(span, op=dist.ReduceOp.SUM, group=group)
+        if average:
+            span /= world
+        return 1
     buckets, cur, cur_bytes = [], [], 0
     for p in params:
         nbytes = p.numel() * 4

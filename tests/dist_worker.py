@@ -59,6 +59,26 @@ def run_grads(rank, world, port, q):
     ok = all(torch.allclose(p.grad, e, rtol=0, atol=1e-7) for p, e in zip(params, expect)) and frozen.grad is None
     n_many = pdist.allreduce_gradients(params, bucket_bytes=512 * 512 * 4)   # second pass: several buckets, values = mean of means
     ok = ok and all(torch.allclose(p.grad, e, rtol=0, atol=1e-7) for p, e in zip(params, expect))
+    # gradients as views of one flat buffer (what PixelNeRFNet.bind_mlp_grads hands out): reduced in place, one collective
+    flat = torch.zeros(sum((torch.Size(s).numel() + 63) // 64 * 64 for s in shapes))
+    off = 0
+    for i, (p, s_) in enumerate(zip(params, shapes)):
+        n = torch.Size(s_).numel()
+        v = flat[off:off + n].view(s_)
+        v.copy_(torch.randn(s_, generator=torch.Generator().manual_seed(100 * rank + i)))
+        p.grad = v
+        off += (n + 63) // 64 * 64
+    ptr0 = flat.data_ptr()
+    n_flat = pdist.allreduce_gradients(params)
+    expect2 = [sum(torch.randn(s_, generator=torch.Generator().manual_seed(100 * r + i)) for r in range(world)) / world
+               for i, s_ in enumerate(shapes)]
+    ok = ok and n_flat == 1 and all(p.grad.data_ptr() >= ptr0 for p in params)
+    ok = ok and all(torch.allclose(p.grad, e, rtol=0, atol=1e-7) for p, e in zip(params, expect2))
+    # ... and when one rank lacks a gradient the ranks agree on the bucket path (same result, no mismatch of collectives)
+    if rank == 1:
+        params[3].grad = None
+    pdist.allreduce_gradients(params)
+    ok = ok and params[3].grad is not None and all(torch.isfinite(p.grad).all() for p in params)
     q.put((rank, bool(ok), n_one, n_many))
     dist.destroy_process_group()
 
