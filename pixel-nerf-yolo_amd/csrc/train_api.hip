@@ -159,6 +159,39 @@ void build_items(TrainPlan& p, int n_tiles, int cus, std::vector<DwItem>& items,
     });
     *n_full = 0;
     for (const DwItem& it : items) *n_full += full(it) ? 1 : 0;
+    // XCD-aware placement of the complete tiles: the four output tiles (mt, nt) of one K split read the same dY rows and X
+    // columns twice each.  Consecutive workgroup ids go round-robin to the 8 XCDs (each with its own L2), so the four tiles of a
+    // split are given ids 8 apart -- same XCD, dispatched together -- and the second read of an operand slab is an L2 hit instead
+    // of another trip over the fabric.  (Groups of other sizes, e.g. lin_z at L = 1792 with 2 x 7 tiles, keep list order.)
+    if (!getenv("PNYOLO_DW_NO_XCD_GROUPS")) {
+        const size_t first = items.size() - (size_t)*n_full;
+        std::vector<DwItem> out(items.begin(), items.begin() + first);
+        std::vector<std::vector<DwItem>> groups;   // pending groups of exactly 4 tiles
+        auto flush = [&]() {
+            if (groups.size() == 8) {
+                for (int j = 0; j < 4; ++j)
+                    for (int g = 0; g < 8; ++g) out.push_back(groups[g][j]);
+            } else {
+                for (auto& g : groups) out.insert(out.end(), g.begin(), g.end());
+            }
+            groups.clear();
+        };
+        size_t i = first;
+        while (i < items.size()) {
+            size_t j = i + 1;
+            while (j < items.size() && j - i < 4 && items[j].job == items[i].job && items[j].tv_lo == items[i].tv_lo) ++j;
+            if (j - i == 4) {
+                groups.emplace_back(items.begin() + i, items.begin() + j);
+                if (groups.size() == 8) flush();
+            } else {
+                flush();
+                out.insert(out.end(), items.begin() + i, items.begin() + j);
+            }
+            i = j;
+        }
+        flush();
+        items.swap(out);
+    }
     *part_floats = poff;
     *bias_floats = boff;
 }
