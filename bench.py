@@ -200,6 +200,7 @@ def train_main(args):
         prof = cProfile.Profile()
         prof.enable()
     t0 = time.perf_counter()
+    step_ms, t_prev = [], t0
     for i in range(steps):
         loss = step(100 + i)
         f = net.last_mlp_stats(full=True)     # NOTE: reading event times waits for the step
@@ -211,6 +212,9 @@ def train_main(args):
             k_fl[1 + j] += b["flops"][j]
         ff, fm = net.last_flush_stats()       # deferred mode: ONE weight-gradient GEMM per MLP over all scenes' tiles
         k_ms[3] += fm
+        t_now = time.perf_counter()
+        step_ms.append((t_now - t_prev) * 1e3)
+        t_prev = t_now
     fence()
     elapsed = time.perf_counter() - t0
     if prof is not None:
@@ -234,6 +238,7 @@ def train_main(args):
     out = {
         "metric": "training rays/sec, 64+32 samples/ray, 3-view 128x128 conditioning", "value": world * SB * RB * steps / elapsed,
         "unit": "rays/s", "n_gpus": world, "n_ranks_seen": dist.get_world_size() if dist.is_initialized() else 1, "steps": steps, "warmup": max(args.warmup, 4), "ms_per_step": elapsed / steps * 1e3,
+        "ms_per_step_min_median_max": [min(step_ms), sorted(step_ms)[len(step_ms) // 2], max(step_ms)],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 (matrix products of forward, dX chain and weight gradients on f16x2 split operands, fp32 accumulate)" if h2_train else "f32",
         "data": "synthetic",
