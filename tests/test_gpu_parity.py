@@ -291,12 +291,12 @@ def test_encoder_golden(golden):
     assert maxabs(lat, g["latent"]) < 2e-5 * scale  # random-weight trunk: activations reach O(100)
 
 
-@pytest.mark.parametrize("n", [40, 4096, 9000])
-def test_f16x2_split_shape_is_bit_identical(golden, n, monkeypatch):
+@pytest.mark.parametrize("fixture,n", [("nerf_c2", 40), ("nerf_c2", 4096), ("nerf_c2", 9000), ("nerf_c3", 4096)])
+def test_f16x2_split_shape_is_bit_identical(golden, fixture, n, monkeypatch):
     """The f16x2 kernel has two tile shapes (csrc/mlp_h2.hip: 8 waves x 64 samples; csrc/mlp_h2s.hip: 4 waves x 32 samples, picked
     for launches of at most 32 x CUs points): the same products in the same order for every sample, so the shape -- and with it
-    the size of the batch a point is evaluated in -- never shows in a result."""
-    g = golden("nerf_c2")
+    the size of the batch a point is evaluated in -- never shows in a result.  (nerf_c3: L = 1792 conditioning.)"""
+    g = golden(fixture)
     monkeypatch.setenv("PNYOLO_PROJECTION", "on")
     monkeypatch.setenv("PNYOLO_MLP_PRECISION", "f16x2")
     rs = np.random.RandomState(n)
