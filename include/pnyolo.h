@@ -34,14 +34,15 @@
 extern "C" {
 #endif
 
-#define PNY_ABI_VERSION 9
+#define PNY_ABI_VERSION 10
 
 typedef enum pny_status {
     PNY_OK = 0,
     PNY_ERR_ARG = -1,      /* bad argument / unsupported configuration */
     PNY_ERR_STATE = -2,    /* call order (e.g. render before weights / latent / cameras) */
     PNY_ERR_HIP = -3,      /* HIP runtime error (message carries hipGetErrorString) */
-    PNY_ERR_NOGPU = -4     /* no gfx950 device visible */
+    PNY_ERR_NOGPU = -4,    /* no gfx950 device visible */
+    PNY_ERR_RANGE = -5     /* an earlier F16X2 launch met a value outside the f16 range (pny_model_range_status) */
 } pny_status;
 
 typedef struct pny_model pny_model;
@@ -261,6 +262,27 @@ int pny_scene_project(pny_scene* s, pny_stream stream);
 int pny_scene_set_precision(pny_scene* s, int mode);
 /* 1 when the last MLP launch of the scene ran the F16X2 kernel. */
 int pny_scene_last_precision(pny_scene* s, int* f16x2);
+
+/* Run-time guard of the F16X2 arithmetic's range.  The split operands are f16 planes: a value of magnitude >= 65520 (or an
+ * infinity) has no f16 representation, and a launch that meets one returns garbage where the reference -- fp32 throughout,
+ * src/model/resnetfc.py:134-186; it only prints when its output holds a NaN, src/model/models.py:174-270 -- still returns
+ * numbers.  Every F16X2 kernel therefore reports what it meets into one word per model that the host can read at any time
+ * (pinned host memory, written with a system-scope atomic OR by the lanes that saw the value):
+ *   PNY_RANGE_ACTIVATION  forward (render / query / training forward): a relu output or a lin_in input left the range;
+ *   PNY_RANGE_GRADIENT    backward: the running max |dY| of a chain / weight-gradient launch is not finite (the chain works
+ *                         in a per-tile scaled domain with 2^11 of headroom, csrc/mlp_bwd_h2.hip);
+ *   PNY_RANGE_WEIGHT      pny_model_refresh repacked a weight of magnitude > 65504 or a NaN (pny_model_finalize checks on the
+ *                         host and keeps AUTO on F32 by itself; a refresh runs on the device, after the launch decision).
+ * pny_model_range_status returns the bits seen so far (`bits`, may be NULL) and, with clear != 0, resets them.  It does not
+ * synchronise: the bits of a launch are complete once that launch has finished (synchronise its stream first).
+ * While bits are set, every scene-level entry point (render, query, encode, backward ...) of the model fails with
+ * PNY_ERR_RANGE -- results computed since the overflow are not to be trusted -- until they are cleared; PNY_RANGE_WEIGHT also
+ * drops AUTO scenes to F32 until the next pny_model_finalize.  Recovery: clear, pny_scene_set_precision(F32), repeat the call
+ * (pixel-nerf-yolo_amd/model.py does this transparently for no-grad calls: `f16_range_policy`). */
+#define PNY_RANGE_ACTIVATION 1u
+#define PNY_RANGE_GRADIENT 2u
+#define PNY_RANGE_WEIGHT 4u
+int pny_model_range_status(pny_model* m, unsigned* bits, int clear);
 
 /* Introspection for bench.py: GEMM FLOPs (2/MAC, unpadded, MLP only) of the last pny_render /
  * pny_query on this scene -- `flops` as executed by the fused kernel, `flops_reference` as the

@@ -295,6 +295,13 @@ int pny_model_create(pny_model** out, const pny_model_desc* desc) {
     PNY_HIP(hipSetDevice(desc->device));
     pny_model* m = new pny_model();
     m->desc = *desc;
+    // f16-range guard word (pny_model_range_status): pinned, device-visible host memory; the kernels OR into it
+    if (hipHostMalloc(reinterpret_cast<void**>(&m->range_flag), 64, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        delete m;
+        return fail(PNY_ERR_HIP, "pny_model_create: hipHostMalloc(range flag) failed");
+    }
+    *m->range_flag = 0;
     *out = m;
     return PNY_OK;
 }
@@ -321,6 +328,7 @@ void pny_model_destroy(pny_model* m) {
     if (m->aux_join) (void)hipEventDestroy(m->aux_join);
     m->enc.release();
     for (float* p : m->zproj_allocs) (void)hipFree(p);
+    if (m->range_flag) (void)hipHostFree(m->range_flag);
     delete m;
 }
 
@@ -468,8 +476,11 @@ int pny_model_refresh(pny_model* m, pny_stream stream) {
             s->last_stream = st;
             s->has_last_stream = true;
         }
+        // an order event recorded BEFORE this refresh (mark_stream_point) no longer covers the scene's stream: a later call
+        // on another stream has to wait for the repack too, so enter_stream must record a fresh event behind it
+        s->order_ev_valid = false;
     }
-    launch_repack(reinterpret_cast<const PackJob*>(m->repack_jobs.p), m->n_repack_jobs, m->repack_max_elems, st);
+    launch_repack(reinterpret_cast<const PackJob*>(m->repack_jobs.p), m->n_repack_jobs, m->repack_max_elems, st, m->range_flag);
     PNY_HIP(hipGetLastError());
     ++m->generation;   // projected maps of every scene are stale
     return PNY_OK;
@@ -748,9 +759,23 @@ int pny_gen_rays(const float* poses_host, int b, int width, int height, const fl
 
 // ---------------------------------------------------------------------------------- MLP launch
 namespace pny {
+static unsigned range_bits(const pny_model* m) {
+    return m->range_flag ? __atomic_load_n(m->range_flag, __ATOMIC_RELAXED) : 0u;
+}
 int check_ready(pny_scene* s, const char* who) {
     if (!s) return fail(PNY_ERR_ARG, std::string(who) + ": null scene");
     if (!s->m->finalized) return fail(PNY_ERR_STATE, std::string(who) + ": weights not finalized (pny_model_finalize)");
+    // f16-range guard: scenes pinned to F32 neither cause nor suffer from it (weights beyond the f16 range are legal there)
+    const unsigned bits = s->precision == PNY_PRECISION_F32 ? 0u : range_bits(s->m);
+    if (bits) {
+        if (bits & PNY_RANGE_WEIGHT) s->m->f16_weights_ok = false;   // AUTO scenes run F32 from here on
+        return fail(PNY_ERR_RANGE, std::string(who) + ": an earlier F16X2 launch left the f16 range (" +
+                                       std::string(bits & PNY_RANGE_ACTIVATION ? "activation " : "") +
+                                       std::string(bits & PNY_RANGE_GRADIENT ? "gradient " : "") +
+                                       std::string(bits & PNY_RANGE_WEIGHT ? "weight " : "") +
+                                       "beyond +-65504 or not finite): its results are invalid.  Clear with pny_model_range_status(m, 0, 1), pin "
+                                       "pny_scene_set_precision(s, PNY_PRECISION_F32) and repeat the call");
+    }
     if (!s->have_latent) return fail(PNY_ERR_STATE, std::string(who) + ": scene has no latent (pny_scene_encode / pny_scene_set_latent)");
     if (!s->have_cams) return fail(PNY_ERR_STATE, std::string(who) + ": scene has no cameras (pny_scene_set_cameras)");
     if (s->cam_ns != s->ns) return fail(PNY_ERR_STATE, std::string(who) + ": camera count != latent view count");
@@ -827,6 +852,7 @@ int fill_mlp_args(pny_scene* s, int mode, const float* xyz, const float* dirs, c
     }
     a.w_base = s->m->packed.f();
     a.w_bytes = (unsigned)s->m->packed.bytes;
+    a.range_flag = s->m->range_flag;
     a.latent = s->latent.f();
     a.zp = nullptr;
     a.zp_stride = view_blocks(d) * HID;
@@ -1145,6 +1171,15 @@ int pny_scene_set_precision(pny_scene* s, int mode) {
         return fail(PNY_ERR_ARG, "pny_scene_set_precision: mode must be PNY_PRECISION_{F32,F16X2,AUTO}");
     if ((mode == PNY_PRECISION_F32) != (s->precision == PNY_PRECISION_F32)) s->zp_valid[0] = s->zp_valid[1] = false;   // re-project in the new arithmetic
     s->precision = mode;
+    return PNY_OK;
+}
+
+int pny_model_range_status(pny_model* m, unsigned* bits, int clear) {
+    if (!m) return fail(PNY_ERR_ARG, "pny_model_range_status: null model");
+    const unsigned b = range_bits(m);
+    if (bits) *bits = b;
+    if (b & PNY_RANGE_WEIGHT) m->f16_weights_ok = false;   // until the next finalize re-checks on the host
+    if (clear && m->range_flag) __atomic_store_n(m->range_flag, 0u, __ATOMIC_RELAXED);
     return PNY_OK;
 }
 

@@ -151,6 +151,7 @@ struct pny_model {
     std::vector<float*> zproj_allocs;
     bool has_zproj = false;
     bool f16_weights_ok = true;   // every MLP weight is representable in the f16 range (checked at finalize; AUTO precision needs it)
+    unsigned* range_flag = nullptr;           // pinned host word the f16x2 kernels report PNY_RANGE_* bits into (pny_model_range_status)
     uint64_t generation = 0;                  // bumped by every finalize (scenes re-project)
 };
 

@@ -223,7 +223,12 @@ __global__ __launch_bounds__(h2::THREADS, 2) void pny_mlp_bwd_h2_kernel(const Bw
     if (a.dy_absmax) {   // non-negative floats order like their bit patterns
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
-        if (lane == 0) atomicMax(a.dy_absmax, __float_as_uint(amax));
+        if (lane == 0) {
+            atomicMax(a.dy_absmax, __float_as_uint(amax));
+            // f16-range guard: a non-finite gradient was written to the dY stash (the split-f16 consumers -- this chain's
+            // scaled planes, the weight-gradient GEMM's scale -- cannot represent it): PNY_RANGE_GRADIENT
+            if (!(amax < 3.0e38f)) range_report(a.range_flag, 2u);
+        }
     }
 }
 

@@ -50,7 +50,7 @@ namespace pny {
 // Diagnostic build only (-DPNY_H2_STAMP): s_memtime brackets around the phases of a tile, summed per wave and printed by
 // launch_mlp_h2.  No stamp executes in the product build.
 #ifdef PNY_H2_STAMP
-enum { HS_TOTAL = 0, HS_GEMM, HS_GATHER_WAIT, HS_GATHER, HS_EPI_WAIT, HS_EPI, HS_PROLOGUE, HS_LINOUT, HS_SLAB, HS_N };
+enum { HS_TOTAL = 0, HS_GEMM, HS_GATHER_WAIT, HS_GATHER, HS_EPI_WAIT, HS_EPI, HS_PROLOGUE, HS_LINOUT, HS_SLAB, HS_REAL, HS_N };
 __device__ unsigned long long* g_h2_stamp_buf;
 __device__ __forceinline__ unsigned long long h2now() {
     unsigned long long t;
@@ -69,6 +69,24 @@ __device__ __forceinline__ unsigned long long h2now() {
 #else
 #define HS_T0()
 #define HS_LAP(cat)
+#endif
+
+// Timing-only experiment (-DPNY_H2_EXP_STAGGER=<cycles>, wrong results): the workgroup barrier replaced by a barrier among the
+// four waves of a half (waves 0-3 / 4-7: the two waves of a SIMD are in different halves), the second half started <cycles>
+// late -- an upper bound for what running the two waves of a SIMD out of phase (one's epilogue / gather under the other's
+// GEMM) can return.  Cross-half dependencies are ignored, so the values are garbage; every address stays valid (both halves
+// write the tap table).
+#ifdef PNY_H2_EXP_STAGGER
+__device__ __forceinline__ void h2group_sync(unsigned* cnt, unsigned& epoch, int wave, int lane) {
+    epoch += 4;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_fetch_add(cnt + (wave >> 2), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(cnt + (wave >> 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < epoch) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+#define H2SYNC() h2group_sync(sync_cnt, sync_epoch, wave, lane)
+#else
+#define H2SYNC() __syncthreads()
 #endif
 
 // The 8-byte slot of feature quad (row, half) = (feature / 8, (feature / 4) & 1) of sample m in plane p is at byte
@@ -92,12 +110,16 @@ __device__ __forceinline__ void stash_store(__amdgpu_buffer_rsrc_t rsrc, unsigne
 // STASH (training forward): relu(acc + ...) is also written in fp32 to `stash` in the [feature/4][sample] float4 tile layout of
 // the backward's operand stash (pny_common.h StashLayout; the same values the fp32 STASH kernel of mlp.hip writes).
 template <bool ADDZ, bool STASH = false>
-__device__ __forceinline__ void h2epilogue(f32x16 (&acc)[h2::NT][h2::MT], const float* bias, char* planes, int wave, int lane,
+__device__ __forceinline__ void h2epilogue(f32x16 (&acc)[h2::NT][h2::MT], const float* bias, char* planes, int wave, int lane, unsigned* range_flag,
                                            __amdgpu_buffer_rsrc_t stash = __amdgpu_buffer_rsrc_t(), unsigned stash_off = 0) {
     using namespace h2;
     const unsigned stash_lane = (unsigned)(((8 * NT * wave + (lane >> 5)) * TM + (lane & 31)) * 16);
     const int m0 = lane & 31, hh = lane >> 5;
     const float* bl = bias + 32 * NT * wave + 4 * hh;
+    // f16-range guard (include/pnyolo.h pny_model_range_status): the largest value this call hands to the f16 split; a relu
+    // output >= 65520 rounds to an f16 infinity.  Local to the call (a register kept across the GEMM loops costs spills
+    // there: 60 -> 169 spilled VGPRs when it was a kernel-wide running maximum); two v_max per quad, one branch per call.
+    float rmax = 0.f;
     // accumulator quad (nt, q) of this lane = features 32 NT wave + 32 nt + 8 q + 4 hh + 0..3: row 4 NT wave + 4 nt + q, half hh
     char* base = planes + (4 * NT * wave) * (2 * ROW_BYTES) + m0 * 16 + 8 * hh;
     // the LDS reads of a (nt, mt) tile -- bias quads, staged projection -- are issued together ahead of its arithmetic
@@ -136,6 +158,7 @@ __device__ __forceinline__ void h2epilogue(f32x16 (&acc)[h2::NT][h2::MT], const 
                 acc[nt][mt][4 * q + 2] = x2;
                 acc[nt][mt][4 * q + 3] = x3;
                 const float r0 = relu1(x0), r1 = relu1(x1), r2 = relu1(x2), r3 = relu1(x3);
+                rmax = fmaxf(fmaxf(rmax, fmaxf(r0, r1)), fmaxf(r2, r3));   // f16-range guard (two v_max3_f32 per quad)
                 if constexpr (STASH) stash_store(stash, stash_lane, stash_off + (unsigned)(((8 * nt + 2 * q) * TM + 32 * mt) * 16), r0, r1, r2, r3);
                 h4 p0, p1;
                 split4(r0, r1, r2, r3, p0, p1);
@@ -144,6 +167,7 @@ __device__ __forceinline__ void h2epilogue(f32x16 (&acc)[h2::NT][h2::MT], const 
             }
         }
     }
+    if (__builtin_expect(!(rmax < 65520.0f), 0)) range_report(range_flag, 1u);
 }
 
 // Cross-view running sum slab of the workgroup (layout of mlp_core.h slab_store / slab_load: register quad q of tile
@@ -209,7 +233,7 @@ __device__ __forceinline__ void h2gather_commit(const GatherTaps<h2::C, 2>& g, c
 // per (view, tile) prologue: the lin_in B operand (positional code, view dirs) as f16 planes in rows 0..7 of each plane, and
 // the tap table; the arithmetic of prologue<C>() in mlp_core.h
 template <bool STASH>
-__device__ __forceinline__ void h2prologue(const MlpArgs& a, int v, long long tile, char* planes, float4* tap_tab, int tid,
+__device__ __forceinline__ void h2prologue(const MlpArgs& a, int v, long long tile, char* planes, float4* tap_tab, int tid, unsigned* range_flag,
                                            __amdgpu_buffer_rsrc_t stash = __amdgpu_buffer_rsrc_t(), unsigned stash_xin = 0, float4* tap_raw = nullptr) {
     using namespace h2;
     constexpr int NPART = THREADS / TM;
@@ -226,17 +250,24 @@ __device__ __forceinline__ void h2prologue(const MlpArgs& a, int v, long long ti
         xc[i] = xr[i] + cam.w2c[4 * i + 3];
         vd[i] = cam.w2c[4 * i + 0] * d[0] + cam.w2c[4 * i + 1] * d[1] + cam.w2c[4 * i + 2] * d[2];
     }
+    float rmax = 0.f;   // f16-range guard: lin_in's inputs (coordinates, view directions) go through the same split
     for (int g = part; g < D_IN_PAD / 4; g += NPART) {
         h4 p0, p1;
         const float e0 = input_entry(4 * g + 0, xr, vd, a.freq_factor, a.num_freqs), e1 = input_entry(4 * g + 1, xr, vd, a.freq_factor, a.num_freqs);
         const float e2 = input_entry(4 * g + 2, xr, vd, a.freq_factor, a.num_freqs), e3 = input_entry(4 * g + 3, xr, vd, a.freq_factor, a.num_freqs);
+        rmax = fmaxf(fmaxf(rmax, fmaxf(fabsf(e0), fabsf(e1))), fmaxf(fabsf(e2), fabsf(e3)));
         split4(e0, e1, e2, e3, p0, p1);
         if constexpr (STASH) stash_store(stash, (unsigned)((g * TM + m) * 16), stash_xin, e0, e1, e2, e3);   // lin_in's B operand, [feature/4][sample]
         char* s0 = planes + (g >> 1) * (2 * ROW_BYTES) + m * 16 + 8 * (g & 1);
         *reinterpret_cast<h4*>(s0) = p0;
         *reinterpret_cast<h4*>(s0 + ROW_BYTES) = p1;
     }
+    if (__builtin_expect(!(rmax < 65520.0f), 0)) range_report(range_flag, 1u);
+#ifdef PNY_H2_EXP_STAGGER
+    if (part == NPART - 1 || part == NPART / 2 - 1) {
+#else
     if (part == NPART - 1) {
+#endif
         float ux, uy;
         if (!a.yolo) {
             ux = -xc[0] / xc[2];
@@ -291,6 +322,16 @@ __global__ __launch_bounds__(h2::THREADS, 2) void PNY_H2_KERNEL(const MlpArgs a)
     float* bias_tab = reinterpret_cast<float*>(smem_raw + ACT_BYTES + TAP_BYTES);   // [b_in, b_fc0[0], b_fc1[0], b_fc0[1], ...][512]
     float4* tap_raw = reinterpret_cast<float4*>(smem_raw + lds_bytes(a.n_blocks));   // STASH only: taps addressing the raw latent
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef PNY_H2_EXP_STAGGER
+    unsigned* sync_cnt = reinterpret_cast<unsigned*>(smem_raw + lds_bytes(a.n_blocks) + TAP_BYTES);
+    unsigned sync_epoch = 0;
+    if (tid < 2) sync_cnt[tid] = 0;
+    __syncthreads();
+    if (wave >= 4) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)(PNY_H2_EXP_STAGGER)) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
     const SlabRef slab = {__builtin_amdgcn_make_buffer_rsrc(a.scratch + (size_t)blockIdx.x * (TM * HID), 0, TM * HID * 4, 0x00020000),
                           (unsigned)((wave * (NT * MT * 16 * 64) + 4 * lane) * 4)};
     const int nb = a.n_blocks;
@@ -320,6 +361,7 @@ __global__ __launch_bounds__(h2::THREADS, 2) void PNY_H2_KERNEL(const MlpArgs a)
     unsigned long long hs_acc[HS_N], hs_t_ = 0;
     for (int i = 0; i < HS_N; ++i) hs_acc[i] = 0;
     const unsigned long long hs_start = h2now();
+    const unsigned long long hs_real0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
 #endif
     if constexpr (LDS_BIAS) {
         for (int i = tid; i < (1 + 2 * nb) * HID; i += THREADS) {
@@ -350,19 +392,19 @@ __global__ __launch_bounds__(h2::THREADS, 2) void PNY_H2_KERNEL(const MlpArgs a)
         auto block_tail = [&](int blk, const H2Seg& after, bool slab_in, int next_c0, unsigned stash_net) {
             HS_T0();
             h2zero<NT, MT>(net);
-            __syncthreads();
+            H2SYNC();
             HS_LAP(HS_EPI_WAIT);
             h2gemm(net, ring, ws, fc0seg(blk), fc1seg(blk), planes, lane);
             HS_LAP(HS_GEMM);
-            __syncthreads();
+            H2SYNC();
             HS_LAP(HS_EPI_WAIT);
-            h2epilogue<false, STASH>(net, fc0_bias(blk), planes, wave, lane, xr, stash_net);
+            h2epilogue<false, STASH>(net, fc0_bias(blk), planes, wave, lane, a.range_flag, xr, stash_net);
             // three exclusive continuations (the running sum of the other views and the prefetched chunk both want the
             // registers of `net`: written as one if / else chain so that the allocator never has to provide for both)
             if (slab_in) {
                 h2slab_load(net, slab);
                 HS_LAP(HS_EPI);
-                __syncthreads();
+                H2SYNC();
                 HS_LAP(HS_EPI_WAIT);
                 h2gemm(h, ring, ws, fc1seg(blk), after, planes, lane);
                 HS_LAP(HS_GEMM);
@@ -374,13 +416,13 @@ __global__ __launch_bounds__(h2::THREADS, 2) void PNY_H2_KERNEL(const MlpArgs a)
                         for (int r = 0; r < 16; ++r) h[nt][mt][r] = net[nt][mt][r] + h[nt][mt][r];
             } else if (next_c0 >= 0) {
                 HS_LAP(HS_EPI);
-                __syncthreads();
+                H2SYNC();
                 HS_LAP(HS_EPI_WAIT);
                 h2gemm(h, ring, ws, fc1seg(blk), after, planes, lane, [&]() { gather_issue<C, 0>(g, next_c0, wave); });
                 HS_LAP(HS_GEMM);
             } else {
                 HS_LAP(HS_EPI);
-                __syncthreads();
+                H2SYNC();
                 HS_LAP(HS_EPI_WAIT);
                 h2gemm(h, ring, ws, fc1seg(blk), after, planes, lane);
                 HS_LAP(HS_GEMM);
@@ -391,10 +433,10 @@ __global__ __launch_bounds__(h2::THREADS, 2) void PNY_H2_KERNEL(const MlpArgs a)
             const unsigned x_view = STASH ? (unsigned)v * (unsigned)a.lay.x_view * 4u : 0u;
             auto act_slot = [&](int i) { return x_view + ((unsigned)a.lay.x_act + (unsigned)i * (unsigned)STASH_SLOT) * 4u; };
             HS_T0();
-            __syncthreads();
-            h2prologue<STASH>(a, v, tile, planes, tap_tab, tid, xr, x_view + (unsigned)a.lay.x_in * 4u, tap_raw);
+            H2SYNC();
+            h2prologue<STASH>(a, v, tile, planes, tap_tab, tid, a.range_flag, xr, x_view + (unsigned)a.lay.x_in * 4u, tap_raw);
             h2zero<NT, MT>(h);
-            __syncthreads();
+            H2SYNC();
             if constexpr (STASH) {
                 // z = the interpolated latent of this view (reference encoder.py:101), the B operand of lin_z's weight
                 // gradient: gathered from the latent itself, 128 channels at a time, two chunks in flight, written straight
@@ -437,7 +479,7 @@ __global__ __launch_bounds__(h2::THREADS, 2) void PNY_H2_KERNEL(const MlpArgs a)
                 // from here two chunks are in flight: the loads of chunk c + 1 are issued before chunk c is blended.
                 const int cb = blk * HID;
                 HS_LAP(HS_GATHER);
-                __syncthreads();  // every wave is done reading the planes (previous GEMM)
+                H2SYNC();  // every wave is done reading the planes (previous GEMM)
                 HS_LAP(HS_GATHER_WAIT);
                 gather_issue<C, 1>(g, cb + GCH, wave);
                 __builtin_amdgcn_sched_barrier(0);
@@ -450,9 +492,9 @@ __global__ __launch_bounds__(h2::THREADS, 2) void PNY_H2_KERNEL(const MlpArgs a)
                 h2gather_commit<0>(g, planes, 2, wave, lane);
                 h2gather_commit<1>(g, planes, 3, wave, lane);
                 HS_LAP(HS_GATHER);
-                __syncthreads();  // projection visible
+                H2SYNC();  // projection visible
                 HS_LAP(HS_GATHER_WAIT);
-                h2epilogue<true, STASH>(h, entry_bias(blk), planes, wave, lane, xr, act_slot(2 * blk));
+                h2epilogue<true, STASH>(h, entry_bias(blk), planes, wave, lane, a.range_flag, xr, act_slot(2 * blk));
                 HS_LAP(HS_EPI);
                 block_tail(blk, after, slab_in, next_c0, act_slot(2 * blk + 1));
             };
@@ -484,17 +526,17 @@ __global__ __launch_bounds__(h2::THREADS, 2) void PNY_H2_KERNEL(const MlpArgs a)
         auto post_slot = [&](int i) { return ((unsigned)a.lay.x_post + (unsigned)i * (unsigned)STASH_SLOT) * 4u; };
         for (int blk = nvb; blk < nb; ++blk) {
             HS_T0();
-            __syncthreads();
+            H2SYNC();
             HS_LAP(HS_EPI_WAIT);
-            h2epilogue<false, STASH>(h, entry_bias(blk), planes, wave, lane, xr, post_slot(2 * (blk - nvb)));
+            h2epilogue<false, STASH>(h, entry_bias(blk), planes, wave, lane, a.range_flag, xr, post_slot(2 * (blk - nvb)));
             HS_LAP(HS_EPI);
             block_tail(blk, blk + 1 < nb ? fc0seg(blk + 1) : s_in, false, -1, post_slot(2 * (blk - nvb) + 1));
         }
         // out = lin_out(relu(h + b_fc1[last])) (reference resnetfc.py:185) + output head (models.py:312-317)
         HS_T0();
-        __syncthreads();
-        h2epilogue<false, STASH>(h, entry_bias(nb), planes, wave, lane, xr, post_slot(2 * (nb - nvb)));
-        __syncthreads();
+        H2SYNC();
+        h2epilogue<false, STASH>(h, entry_bias(nb), planes, wave, lane, a.range_flag, xr, post_slot(2 * (nb - nvb)));
+        H2SYNC();
         for (int idx = tid; idx < a.d_out * TM; idx += THREADS) {
             const int o = idx / TM, m = idx % TM;
             const float4* wrow = reinterpret_cast<const float4*>(a.w.w_out + (size_t)o * HID);
@@ -520,6 +562,9 @@ __global__ __launch_bounds__(h2::THREADS, 2) void PNY_H2_KERNEL(const MlpArgs a)
                 else if (o == 3)
                     sum = fmaxf(sum, 0.f);
             }
+#ifdef PNY_H2_EXP_STAGGER
+            if (!(fabsf(sum) < 1e3f)) sum = 0.5f;   // (timing experiment: keep the garbage finite so that the fine pass samples real points)
+#endif
             const long long s = tile * TM + m;
             if (s < a.n_points) a.out[s * a.d_out + o] = sum;
         }
@@ -527,6 +572,7 @@ __global__ __launch_bounds__(h2::THREADS, 2) void PNY_H2_KERNEL(const MlpArgs a)
     }
 #ifdef PNY_H2_STAMP
     hs_acc[HS_TOTAL] = h2now() - hs_start;
+    hs_acc[HS_REAL] = __builtin_amdgcn_s_memrealtime() - hs_real0;
     if (lane == 0)
         for (int i = 0; i < HS_N; ++i) g_h2_stamp_buf[((size_t)blockIdx.x * (THREADS / 64) + wave) * HS_N + i] = hs_acc[i];
 #endif
@@ -542,7 +588,11 @@ static void launch_mlp_h2_t(const MlpArgs& a, int grid, hipStream_t st) {
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
     dev_ &= 63;
+#ifdef PNY_H2_EXP_STAGGER
+    const int extra = h2::TAP_BYTES + 64;
+#else
     const int extra = STASH ? h2::TAP_BYTES : 0;   // second tap table
+#endif
     if (!attr_set[dev_]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(PNY_H2_KERNEL<STASH>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   h2::lds_bytes(h2::MAX_NB) + extra);
@@ -566,10 +616,11 @@ static void launch_mlp_h2_t(const MlpArgs& a, int grid, hipStream_t st) {
         (void)hipMemcpy(hst.data(), dbuf, nst * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         double sum[HS_N] = {0};
         for (size_t i = 0; i < nst; ++i) sum[i % HS_N] += (double)hst[i];
-        static const char* names[HS_N] = {"total", "gemm", "gather-barrier-wait", "gather", "epilogue-barrier-wait", "epilogue", "prologue", "lin_out", "slab"};
+        static const char* names[HS_N] = {"total", "gemm", "gather-barrier-wait", "gather", "epilogue-barrier-wait", "epilogue", "prologue", "lin_out", "slab", "realtime"};
         fprintf(stderr, "[h2 stamp%s, %d x %d] tiles=%d grid=%d:", STASH ? ", stash" : "", h2::NT, h2::MT, a.n_tiles, grid);
         for (int i = 0; i < HS_N; ++i) fprintf(stderr, " %s=%.1f%%", names[i], 100.0 * sum[i] / sum[0]);
-        fprintf(stderr, " (mean wave cycles %.4g)\n", sum[0] / ((double)grid * NWV));
+        fprintf(stderr, " (mean wave cycles %.4g; in-kernel clock %.3f GHz = wave cycles / s_memrealtime ticks x 100 MHz)\n",
+                sum[0] / ((double)grid * NWV), sum[0] / sum[HS_REAL] * 0.1);
     }
 #endif
 }

@@ -71,6 +71,23 @@ __device__ __forceinline__ void h2ring_fill(H2Ring& r, const WStream& ws, const 
 // acc += W_slice . act over segment `cur` (its 16-k steps a multiple of the ring depth); leaves the ring holding the first
 // WD - 1 steps of `next`.  Per step and accumulator tile: x1 w1 + x2 w1 + x1 w2.  Static ring slots as in gemm_run
 // (mlp_core.h): slot d is consumed by step j + d while slot d - 1 is refilled with step j + d - 1 + WD.
+// Timing-only experiment (-DPNY_H2_EXP_MFMA16, wrong results): every 32x32x16 MFMA replaced by two 16x16x32 MFMAs on the
+// same operand registers (the same FLOPs and operand traffic) -- what the chip's clock does with the other MFMA shape.
+#ifdef PNY_H2_EXP_MFMA16
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x16 h2mfma(h8 a, h8 b, f32x16 c) {
+    f32x4v c0 = {c[0], c[1], c[2], c[3]}, c1 = {c[4], c[5], c[6], c[7]};
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c1, 0, 0, 0);
+    c[0] = c0[0]; c[1] = c0[1]; c[2] = c0[2]; c[3] = c0[3];
+    c[4] = c1[0]; c[5] = c1[1]; c[6] = c1[2]; c[7] = c1[3];
+    return c;
+}
+#define PNY_H2_MFMA_PER 2
+#else
+__device__ __forceinline__ f32x16 h2mfma(h8 a, h8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+#define PNY_H2_MFMA_PER 1
+#endif
 struct NoSide {
     __device__ __forceinline__ void operator()() const {}
 };
@@ -113,11 +130,11 @@ __device__ __forceinline__ void h2gemm(f32x16 (&acc)[h2::NT][h2::MT], H2Ring& r,
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r.f[d][nt][0], B[d & 1][mt][0], acc[nt][mt], 0, 0, 0);
+                    acc[nt][mt] = h2mfma(r.f[d][nt][0], B[d & 1][mt][0], acc[nt][mt]);
 #ifndef PNY_H2_NOSCHED
 #pragma unroll
             for (int i = 0; i < NT * MT; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, PNY_H2_MFMA_PER, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, NT * 2 / (NT * MT), 0);   // the step's NT x 2 weight loads
                 __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);
             }
@@ -129,11 +146,11 @@ __device__ __forceinline__ void h2gemm(f32x16 (&acc)[h2::NT][h2::MT], H2Ring& r,
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r.f[d][nt][0], B[d & 1][mt][1], acc[nt][mt], 0, 0, 0);
+                    acc[nt][mt] = h2mfma(r.f[d][nt][0], B[d & 1][mt][1], acc[nt][mt]);
 #ifndef PNY_H2_NOSCHED
 #pragma unroll
             for (int i = 0; i < NT * MT; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, PNY_H2_MFMA_PER, 0);
                 if (i < 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);
             }
@@ -147,11 +164,11 @@ __device__ __forceinline__ void h2gemm(f32x16 (&acc)[h2::NT][h2::MT], H2Ring& r,
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r.f[d][nt][1], B[d & 1][mt][0], acc[nt][mt], 0, 0, 0);
+                    acc[nt][mt] = h2mfma(r.f[d][nt][1], B[d & 1][mt][0], acc[nt][mt]);
 #ifndef PNY_H2_NOSCHED
 #pragma unroll
             for (int i = 0; i < NT * MT; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, PNY_H2_MFMA_PER, 0);
                 if (MT > 1 && i < 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);
             }

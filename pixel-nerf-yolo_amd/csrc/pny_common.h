@@ -89,6 +89,8 @@ struct MlpArgs {
     const float* h2_in;
     const float* h2_fc0[MAX_BLOCKS];
     const float* h2_fc1[MAX_BLOCKS];
+    // f16-range guard (include/pnyolo.h pny_model_range_status): host-visible word the f16x2 kernels OR PNY_RANGE_* bits into
+    unsigned* range_flag;
     // Source-view cameras travel in the kernel-argument segment (NS entries used; 64 B each): a launch carries its own
     // copy, so pny_scene_set_cameras touches no device memory (no copy, no synchronisation, no stream to order against)
     Cam cams[MAX_VIEWS];
@@ -102,7 +104,7 @@ struct PackJob {
     float* dst;
     int kind, n_out, k_in, k_pad, count;
 };
-void launch_repack(const PackJob* jobs_dev, int n_jobs, long long max_elems, hipStream_t st);
+void launch_repack(const PackJob* jobs_dev, int n_jobs, long long max_elems, hipStream_t st, unsigned* range_flag = nullptr);
 
 // ---- backward pass (mlp_bwd.hip)
 struct BwdArgs {
@@ -125,6 +127,7 @@ struct BwdArgs {
     int n_tiles;
     int NS, n_blocks, combine_layer, d_out, yolo;
     unsigned* dy_absmax;              // optional: atomic max of the bit pattern of |v| over everything written to the dY stash
+    unsigned* range_flag;             // f16-range guard word of the model (see MlpArgs)
 };
 // One weight-gradient GEMM: C[a_rows][x_cols] = sum over (tile, view) dY_slot^T X_slot.
 struct DwJob {
@@ -213,6 +216,11 @@ void launch_gen_rays(const float* cam16_host, int b, int w, int h, float znear, 
                      hipStream_t st, long long first, long long count);
 void launch_nchw_to_nhwc(const float* in, float* out, int n, int c, int hw, hipStream_t st);
 void launch_nhwc_to_nchw(const float* in, float* out, int n, int c, int hw, hipStream_t st);
+
+// f16-range guard: bits of include/pnyolo.h PNY_RANGE_*; the word lives in pinned host memory (system-scope atomic)
+__device__ __forceinline__ void range_report(unsigned* flag, unsigned bit) {
+    if (flag) __hip_atomic_fetch_or(flag, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // error plumbing
 void set_error(const std::string& msg);

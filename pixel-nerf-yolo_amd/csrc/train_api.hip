@@ -401,6 +401,7 @@ int mlp_backward(pny_scene* s, int mode, const float* xyz, const float* dirs, co
         b.d_out = d.d_out;
         b.yolo = d.yolo;
         b.dy_absmax = absmax;
+        b.range_flag = m->range_flag;
         if (absmax && !(defer || have_x)) PNY_HIP(hipMemsetAsync(absmax, 0, sizeof(unsigned), st));
         if (dw_h2 && m->f16_weights_ok) {   // split-f16 chain (weights beyond the f16 range: fp32 chain)
             b.h2T_out = wt.h2T_out;
@@ -570,7 +571,10 @@ int pny_query_backward(pny_scene* s, const float* xyz_dev, const float* viewdirs
     if ((rc = enter_stream(s, (hipStream_t)stream))) return rc;
     s->bev_used = 0;
     s->bwd_flops[0] = s->bwd_flops[1] = s->bwd_flops[2] = 0.0;
-    return mlp_backward(s, 0, xyz_dev, viewdirs_dev, nullptr, nullptr, 1, n, coarse, d_out_dev, accumulate, (hipStream_t)stream);
+    // immediate: a deferred reservation that a training pny_render left outstanding belongs to that render's backward; this
+    // call's weight gradients go straight into the buffers bound now
+    return mlp_backward(s, 0, xyz_dev, viewdirs_dev, nullptr, nullptr, 1, n, coarse, d_out_dev, accumulate & 1, (hipStream_t)stream,
+                        nullptr, 0, nullptr, nullptr, nullptr, true);
 }
 
 int pny_composite_backward(const float* rays_dev, const float* z_dev, const float* sample_dev, int64_t n, int k, int white_bkgd,
@@ -680,7 +684,8 @@ int pny_yolo_render_backward(pny_scene* s, const float* rays_dev, int64_t n, int
     launch_sample_coarse(rays_dev, n, n_coarse, 0, u_coarse_dev, seed, z, st);   // the forward's depths (same draws)
     launch_yolo_aggregate_bwd(raw_dev, g_out_dev, n, n_coarse, d.d_out / 7, s->d_samp.f(), st);
     PNY_HIP(hipGetLastError());
-    return mlp_backward(s, 1, nullptr, nullptr, rays_dev, z, n_coarse, (long long)n * n_coarse, 1, s->d_samp.f(), accumulate, st);
+    return mlp_backward(s, 1, nullptr, nullptr, rays_dev, z, n_coarse, (long long)n * n_coarse, 1, s->d_samp.f(), accumulate & 1, st,
+                        nullptr, 0, nullptr, nullptr, nullptr, true);   // immediate (see pny_query_backward)
 }
 
 int pny_scene_last_backward_stats(pny_scene* s, double flops[3], double kernel_ms[3]) {

@@ -100,7 +100,11 @@ def _common_flat_span(params):
     if any(a[1] > b[0] for a, b in zip(ivs, ivs[1:])):   # overlapping views: not a partition of the range
         return None
     lo, hi = ivs[0][0], ivs[-1][1]
-    if (hi - lo) > 2 * sum(g.numel() for g in grads):       # mostly foreign memory between the views: not worth it
+    # The range is reduced (and divided) in place, so it must hold nothing but these gradients: neighbouring views may be
+    # separated only by the allocation's alignment padding (bind_mlp_grads rounds every view up to 64 floats; those gaps
+    # are zeros on every rank).  A wider gap is memory of somebody else -- e.g. the gradient of a parameter that was not
+    # passed in -- and would be summed over the ranks as a side effect: take the bucket path then.
+    if any(b[0] - a[1] >= 64 for a, b in zip(ivs, ivs[1:])):
         return None
     return torch.empty(0, dtype=torch.float32, device=grads[0].device).set_(st, lo, (hi - lo,))
 

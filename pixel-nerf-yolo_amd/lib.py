@@ -98,6 +98,7 @@ SIGNATURES = {
     "pny_scene_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "pny_scene_bind_latent_grad": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pny_scene_last_precision": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "pny_model_range_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint), C.c_int]),
     "pny_scene_project": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pny_scene_last_mlp_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                            C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -118,13 +119,20 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 9
+ABI_VERSION = 10
 PROJECTION = {"off": 0, "on": 1, "auto": 2}
 PRECISION = {"f32": 0, "f16x2": 1, "auto": 2}
 
 
+RANGE_BITS = {1: "activation", 2: "gradient", 4: "weight"}   # include/pnyolo.h PNY_RANGE_*
+
+
 class PnyError(RuntimeError):
     pass
+
+
+class PnyRangeError(PnyError):
+    """An F16X2 launch met a value outside the f16 range (include/pnyolo.h pny_model_range_status)."""
 
 
 def build(verbose=False):
@@ -162,6 +170,8 @@ def load():
 
 
 def check(rc):
+    if rc == -5:   # PNY_ERR_RANGE
+        raise PnyRangeError("libpnyolo: %s (status %d)" % (load().pny_last_error().decode("utf-8", "replace"), rc))
     if rc != 0:
         raise PnyError("libpnyolo: %s (status %d)" % (load().pny_last_error().decode("utf-8", "replace"), rc))
 

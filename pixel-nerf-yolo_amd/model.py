@@ -10,6 +10,7 @@ the C ABI (include/pnyolo.h).  Forward only -- a call under autograd raises (bac
 "next" row of SURVEY.md 8f).
 """
 import ctypes as C
+import os
 import os.path as osp
 import warnings
 
@@ -260,6 +261,12 @@ class PixelNeRFNet(nn.Module):
         self._synced_key = None
         self._dev_bound = False
         self._timing = False
+        # What a no-grad call does when one of its F16X2 launches met a value outside the f16 range (include/pnyolo.h
+        # pny_model_range_status): 'relaunch' (default) = wait for the call, and if the guard fired repeat it on the fp32
+        # kernels with a warning, keeping the scenes pinned to f32 from then on; 'raise' = wait and raise PnyRangeError;
+        # 'lazy' = do not wait: the next library call on the model fails with PNY_ERR_RANGE (what training calls always do --
+        # their launches overlap on side streams).  Env PNYOLO_F16_RANGE.
+        self.f16_range_policy = os.environ.get("PNYOLO_F16_RANGE", "relaunch")
         self._projection = None  # None = library default (auto, or env PNYOLO_PROJECTION)
         self._precision = None   # None = library default (auto, or env PNYOLO_MLP_PRECISION)
 
@@ -393,6 +400,55 @@ class PixelNeRFNet(nn.Module):
         for s in self._h_scenes:
             check(_lib.load().pny_scene_set_precision(s, _lib.PRECISION[mode]))
         return self
+
+    def range_status(self, clear=False):
+        """Bits (include/pnyolo.h PNY_RANGE_*) the F16X2 kernels of this model have reported so far; does not synchronise."""
+        if self._h_model is None:
+            return 0
+        v = C.c_uint(0)
+        check(_lib.load().pny_model_range_status(self._h_model, C.byref(v), int(bool(clear))))
+        return int(v.value)
+
+    def check_f16_range(self):
+        """Wait for the device and raise PnyRangeError if an F16X2 launch left the f16 range since the last clear."""
+        if self._h_model is None:
+            return
+        torch.cuda.synchronize(self._device())
+        bits = self.range_status(clear=True)
+        if bits:
+            raise _lib.PnyRangeError(self._range_message(bits))
+
+    @staticmethod
+    def _range_message(bits):
+        what = ", ".join(n for b, n in sorted(_lib.RANGE_BITS.items()) if bits & b)
+        return ("an F16X2 launch met a value outside the f16 range (%s: |x| >= 65520, infinite or NaN); its results are "
+                "invalid.  Pin the fp32 kernels with net.set_matrix_precision('f32') (or PNYOLO_MLP_PRECISION=f32)" % what)
+
+    def guard_f16_range(self, call):
+        """Runs a no-grad render / query (`call`, repeatable) under `f16_range_policy` and returns its result.  The guard can
+        fire in two places: inside the call, when the flag was already up when it entered the library (a weight repacked out
+        of range by the refresh of this very call, a lazily reported earlier launch: PnyRangeError from the library), or
+        after it, when one of its own F16X2 launches met the value (found by waiting for the stream)."""
+        pol = self.f16_range_policy
+        try:
+            out = call()
+            if pol == "lazy" or not any(self.last_launch_f16x2(i) for i in range(len(self._h_scenes))):
+                return out
+            torch.cuda.current_stream(self._device()).synchronize()
+            bits = self.range_status(clear=False)
+            if not bits:
+                return out
+        except _lib.PnyRangeError:
+            if pol != "relaunch":
+                raise
+            bits = self.range_status(clear=False)
+        self.range_status(clear=True)
+        if pol == "raise":
+            raise _lib.PnyRangeError(self._range_message(bits))
+        warnings.warn("libpnyolo: " + self._range_message(bits) + " -- repeating the call on the fp32 kernels; this model "
+                      "stays on them (f16_range_policy = 'relaunch')")
+        self.set_matrix_precision("f32")
+        return call()
 
     def last_launch_f16x2(self, scene=0):
         """True when the last MLP launch of scene `scene` ran the f16x2 kernel."""
@@ -652,7 +708,7 @@ class PixelNeRFNet(nn.Module):
                     self.check_differentiable()
                 return _QueryFunction.apply(self, xyz, bool(coarse), viewdirs, len(params), *[p for _, p in params],
                                             *([lat] if lat is not None else []))
-        return self._query(xyz, coarse, viewdirs)
+        return self.guard_f16_range(lambda: self._query(xyz, coarse, viewdirs))
 
     def _query(self, xyz, coarse, viewdirs):
         self._sync()

@@ -98,9 +98,11 @@ class _RenderFunction(torch.autograd.Function):
         # call computes its weight gradients immediately (accumulate bit 1), scene after scene, with recompute.
         deferred = ctx.deferred and getattr(model, "_defer_token", None) == ctx.token
         acc = 1 if deferred else 3
-        streams = model.fork_streams(SB) if deferred else [None] * SB
-        # d loss / d latent, accumulated by every scene's call into its own slice (channel-last)
+        # d loss / d latent, accumulated by every scene's call into its own slice (channel-last).  Its zero fill runs on the
+        # current stream, so it is enqueued BEFORE the side streams fork from that stream: scenes 1.. add into the buffer
+        # with atomics from their own streams, and nothing else would order those behind the fill.
         lat_grad = model.begin_latent_grad(ctx.lat_meta, SB) if ctx.lat_meta is not None else None
+        streams = model.fork_streams(SB) if deferred else [None] * SB
         for sb in range(SB):
             with torch.cuda.stream(streams[sb]):
                 s_ = _lib.RenderSaved(z_coarse=sv["z_coarse"][sb].data_ptr(), sample_coarse=sv["sample_coarse"][sb].data_ptr())
@@ -162,8 +164,12 @@ class NeRFRenderer(torch.nn.Module):
         params = model.trainable_mlp_parameters() if grad_mode else []
         lat_src = model.differentiable_latent()
         if not params and lat_src is None:
-            res, _ = self._render(model, rays, want_weights, save=False)
-            return res
+            draws, calls = self.draws, self._calls
+
+            def call():   # repeatable: the same draws / seeds when the f16-range guard asks for the call again
+                self.draws, self._calls = draws, calls
+                return self._render(model, rays, want_weights, save=False)[0]
+            return model.guard_f16_range(call)
         if lat_src is None:
             model.check_differentiable()     # (with a differentiable latent the caller's own encoder takes the gradient)
         kf = int(self.n_fine) if (self.using_fine and self.n_fine > 0) else 0
@@ -339,7 +345,12 @@ class YoloRenderer(torch.nn.Module):
             if lat is None:
                 net.check_differentiable()
             return _YoloRenderFunction.apply(self, rays, len(params), *[p for _, p in params], *([lat] if lat is not None else []))
-        return self._render(rays)[0]
+        draws, calls = self.draws, self._calls
+
+        def call():
+            self.draws, self._calls = draws, calls
+            return self._render(rays)[0]
+        return net.guard_f16_range(call)
 
     def _render(self, rays, keep_raw=False):
         net = self.net

@@ -74,6 +74,11 @@ def run_grads(rank, world, port, q):
                for i, s_ in enumerate(shapes)]
     ok = ok and n_flat == 1 and all(p.grad.data_ptr() >= ptr0 for p in params)
     ok = ok and all(torch.allclose(p.grad, e, rtol=0, atol=1e-7) for p, e in zip(params, expect2))
+    # a SUBSET of the flat allocation's views (params[2] is left out): its storage lies between the views passed in, so the
+    # in-place span must not be taken -- the un-passed gradient keeps its rank-local value
+    before = params[2].grad.clone()
+    pdist.allreduce_gradients([params[0], params[1], params[3], params[4]])
+    ok = ok and torch.equal(params[2].grad, before)
     # ... and when one rank lacks a gradient the ranks agree on the bucket path (same result, no mismatch of collectives)
     if rank == 1:
         params[3].grad = None

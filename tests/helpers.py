@@ -123,3 +123,42 @@ def check_against_nerf_golden(g, out, dbg, tol, max_flips=2):
         assert maxabs(out["fine"][k][0].cpu()[good], g["fine_" + k][good]) < tol, k
     assert maxabs(out["fine"]["rgb"][0], g["fine_rgb"]) < 2e-2   # a moved sample changes the quadrature, not the scene
     return bad
+
+
+# --------------------------------------------------------------------------- relu-safe points / rays (gradient comparisons)
+def clean_points(sc, xyz, vd, n, ambig=1e-5):
+    """First n of the candidate points whose relu inputs (both MLPs, traced through the oracle) all satisfy |h| >= ambig."""
+    import pnyolo_oracle as orc
+    orc.RELU_TRACE = []
+    with torch.no_grad():
+        orc.query(sc, xyz, vd, coarse=True)
+        if sc.mlp_fine is not None:
+            orc.query(sc, xyz, vd, coarse=False)
+    ok = torch.stack(orc.RELU_TRACE).min(dim=0)[0] >= ambig
+    orc.RELU_TRACE = None
+    idx = ok.nonzero().flatten()[:n]
+    assert idx.numel() == n, "not enough unambiguous candidates (%d of %d)" % (int(ok.sum()), len(xyz))
+    return idx.numpy()
+
+
+def clean_rays(sc, rays, kc, kf, kfd, draws, n, chunk=160, ambig=1e-5, **kw):
+    """First n of the candidate rays all of whose samples (coarse and fine pass) are unambiguous.  Rays are independent in the
+    oracle, so the candidates are traced chunk by chunk and the search stops once n are found (the oracle on the CPU is what
+    these tests spend their time in)."""
+    import pnyolo_oracle as orc
+    found, N = [], rays.shape[0]
+    for lo in range(0, N, chunk):
+        hi = min(N, lo + chunk)
+        orc.RELU_TRACE = []
+        kw_c = {k: (v[lo:hi] if hasattr(v, "shape") and len(v.shape) > 0 and v.shape[0] == N else v) for k, v in kw.items()}
+        with torch.no_grad():
+            orc.render(sc, rays[lo:hi], kc, kf, kfd, draws["u_coarse"][lo:hi], draws["u_fine"][lo:hi], draws["u_fine2"][lo:hi],
+                       draws["g_depth"][lo:hi], **kw_c)
+        ok = torch.ones(hi - lo, dtype=torch.bool)
+        for t in orc.RELU_TRACE:                   # (n*K,) per traced relu; K = kc or kc + kf
+            ok &= t.reshape(hi - lo, -1).min(dim=1)[0] >= ambig
+        orc.RELU_TRACE = None
+        found += (ok.nonzero().flatten() + lo).tolist()
+        if len(found) >= n:
+            return np.asarray(found[:n])
+    raise AssertionError("not enough unambiguous rays (%d of %d)" % (len(found), N))

@@ -6,12 +6,14 @@ tests/test_oracle_golden.py::test_training_gradients), and against the reference
 
 Tolerance: every gradient tensor within 1e-4 x its own max |.| (gradients sum 10^4..10^5 fp32 products).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
 
 import pnyolo_oracle as orc
-from helpers import DEV, dt, load_mlp, maxabs
+from helpers import DEV, clean_points, clean_rays, dt, load_mlp, maxabs
 from pixel_nerf_yolo_amd import conf as pconf
 from pixel_nerf_yolo_amd import lib as plib
 from pixel_nerf_yolo_amd import synth
@@ -20,12 +22,6 @@ from pixel_nerf_yolo_amd.render import NeRFRenderer
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-4
-
-
-# tests that run under both backward arithmetics; every other test runs the split-f16 backward (the default of scenes that are
-# not pinned to F32) only
-BOTH_BACKWARD_ARITHMETICS = {"test_query_backward_vs_oracle_autograd", "test_render_backward_vs_oracle",
-                             "test_training_gradients_reference_golden", "test_weight_gradients_f16x2_any_gradient_scale"}
 
 
 @pytest.fixture(autouse=True, params=["dw_f32", "dw_f16x2"])
@@ -40,9 +36,7 @@ def training_forward_arithmetic(request, monkeypatch):
         monkeypatch.setenv("PNYOLO_MLP_PRECISION", "f32")
     # The backward's matrix products (dX chain, weight gradients) run on the fp32 MFMA and on the split-f16 matrix path
     # (csrc/mlp_bwd_h2.hip, pny_dw_gemm_h2_kernel: gradients scaled by powers of two), the latter being the default of scenes
-    # that are not pinned to F32.  Same oracle, same tolerances.
-    if request.param == "dw_f32" and request.node.originalname not in BOTH_BACKWARD_ARITHMETICS:
-        pytest.skip("fp32 backward leg: run for the core gradient comparisons only (suite time)")
+    # that are not pinned to F32.  Same oracle, same tolerances; EVERY test of this module runs under both.
     monkeypatch.setenv("PNYOLO_BWD_PRECISION", "f32" if request.param == "dw_f32" else "f16x2")
 
 
@@ -96,43 +90,12 @@ def test_composite_backward_vs_autograd(K, white):
 # sample moves a gradient tensor by ~1/n_samples of its scale.  With ~10^4 relu units per query point about 7 % of
 # random points have a unit with |h| < 1e-5.  The comparisons below therefore run on points / rays whose every
 # pre-activation (traced through the oracle, pnyolo_oracle.RELU_TRACE) is at least AMBIG away from zero.
-AMBIG = 1e-5
-
-
-def clean_points(sc, xyz, vd, n):
-    """First n of the candidate points whose relu inputs (both MLPs) all satisfy |h| >= AMBIG."""
-    orc.RELU_TRACE = []
-    with torch.no_grad():
-        orc.query(sc, xyz, vd, coarse=True)
-        if sc.mlp_fine is not None:
-            orc.query(sc, xyz, vd, coarse=False)
-    ok = torch.stack(orc.RELU_TRACE).min(dim=0)[0] >= AMBIG
-    orc.RELU_TRACE = None
-    idx = ok.nonzero().flatten()[:n]
-    assert idx.numel() == n, "not enough unambiguous candidates (%d of %d)" % (int(ok.sum()), len(xyz))
-    return idx.numpy()
-
-
-def clean_rays(sc, rays, kc, kf, kfd, draws, n, chunk=160, **kw):
-    """First n of the candidate rays all of whose samples (coarse and fine pass) are unambiguous.  Rays are independent in the
-    oracle, so the candidates are traced chunk by chunk and the search stops once n are found (the oracle on the CPU is what
-    these tests spend their time in)."""
-    found, N = [], rays.shape[0]
-    for lo in range(0, N, chunk):
-        hi = min(N, lo + chunk)
-        orc.RELU_TRACE = []
-        kw_c = {k: (v[lo:hi] if hasattr(v, "shape") and len(v.shape) > 0 and v.shape[0] == N else v) for k, v in kw.items()}
-        with torch.no_grad():
-            orc.render(sc, rays[lo:hi], kc, kf, kfd, draws["u_coarse"][lo:hi], draws["u_fine"][lo:hi], draws["u_fine2"][lo:hi],
-                       draws["g_depth"][lo:hi], **kw_c)
-        ok = torch.ones(hi - lo, dtype=torch.bool)
-        for t in orc.RELU_TRACE:                   # (n*K,) per traced relu; K = kc or kc + kf
-            ok &= t.reshape(hi - lo, -1).min(dim=1)[0] >= AMBIG
-        orc.RELU_TRACE = None
-        found += (ok.nonzero().flatten() + lo).tolist()
-        if len(found) >= n:
-            return np.asarray(found[:n])
-    raise AssertionError("not enough unambiguous rays (%d of %d)" % (len(found), N))
+AMBIG = 1e-5   # fp32 reference-order forward (agrees with the oracle's pre-activations to ~1e-6)
+# The shipped DEFAULT training arithmetic (f16x2 kernel on the projected latent: another evaluation order, split-f16 matrix
+# products) reproduces the oracle's pre-activations to ~1e-5 instead of ~1e-6, so its comparisons select points / rays with a
+# wider margin.  Measured (tools/debug/margin_sweep.sh, profiles/r03_margin_sweep.log): the worst gradient error of the
+# default path against autograd through the oracle stops depending on the margin from 2e-5 on; 5e-5 is used.
+AMBIG_DEFAULT = float(os.environ.get("PNYOLO_TEST_AMBIG_DEFAULT", "5e-5"))
 
 
 # --------------------------------------------------------------------------- MLP (query) backward
@@ -830,3 +793,129 @@ def test_render_with_sigma_noise_forward_and_backward():
     with torch.no_grad():
         ev = ren(net, rays[None].to(DEV), want_weights=True)
     assert maxabs(ev["coarse"]["weights"][0], quiet["coarse"]["weights"].detach()) < 1e-4
+
+
+# --------------------------------------------------------------------------- the shipped DEFAULT training arithmetic vs the oracle
+# Everything above that compares with torch.autograd through the oracle pins the fp32 reference-order training forward (fixture
+# `training_forward_arithmetic`).  The tests below keep what a user gets without touching a knob -- f16x2 projected forward
+# (with the stash written from its epilogues for the renderer), f16x2 dX chain, f16x2 weight-gradient GEMMs -- and hold it to
+# the same oracle at the same 1e-4 x max |gradient| for all 30 / 60 parameter tensors, on points / rays selected with the wider
+# relu margin AMBIG_DEFAULT (see the comment at its definition).
+@pytest.mark.f16x2_forward
+@pytest.mark.parametrize("cfg", [
+    dict(ns=2, L=512, n=200),                       # the shipped multi-view shape
+    dict(ns=3, L=512, n=65),                        # ragged tile
+    dict(ns=2, L=1792, n=70, lat_hw=(8, 8)),        # YOLO-sized conditioning
+])
+def test_query_backward_default_arithmetic_vs_oracle(cfg):
+    if os.environ.get("PNYOLO_BWD_PRECISION") == "f32":
+        pytest.skip("the default backward is the split-f16 one")
+    n = cfg["n"]
+    net, sc = scene_pair(cfg["ns"], 32, 40, cfg["L"], 4, 5, 3, 2500 + n, lat_hw=cfg.get("lat_hw"))
+    rs = np.random.RandomState(n + 1)
+    xyz = rs.uniform(-0.5, 0.5, size=(5 * n + 100, 3)).astype(np.float32)
+    vd = rs.standard_normal((5 * n + 100, 3)).astype(np.float32)
+    keep = clean_points(sc, xyz, vd, n, ambig=AMBIG_DEFAULT)
+    xyz, vd = xyz[keep], vd[keep]
+    G = rs.standard_normal((n, 4)).astype(np.float32)
+    worst = 0.0
+    for coarse in (True, False):
+        net.zero_grad()
+        out = net(dt(xyz)[None], coarse=coarse, viewdirs=dt(vd)[None])
+        assert net.last_launch_f16x2(), "the default forward is the f16x2 kernel"
+        (out[0] * dt(G)).sum().backward()
+        for m_ in (sc.mlp_coarse, sc.mlp_fine):
+            for v in m_.values():
+                v.grad = None
+        ref = orc.query(sc, xyz, vd, coarse=coarse)
+        assert maxabs(out[0], ref.detach()) < 1e-4
+        (ref * torch.from_numpy(G)).sum().backward()
+        worst = max(worst, compare_param_grads(net, sc, which=("mlp_coarse",) if coarse else ("mlp_fine",)))
+    print("default arithmetic, query backward, margin %.0e: worst gradient error %.2e of the tensor's max" % (AMBIG_DEFAULT, worst))
+
+
+@pytest.mark.f16x2_forward
+@pytest.mark.parametrize("with_depth,L", [(False, 512), (True, 512), (True, 1792)])
+def test_render_backward_default_arithmetic_vs_oracle(with_depth, L):
+    """pny_render_backward as shipped (f16x2 stash forward, f16x2 chain and weight gradients, depth samples attached: the
+    reference's graph) against autograd through the oracle: all 60 parameter tensors within 1e-4 of their max.  Few samples
+    per ray (6 + 4) so that rays with EVERY pre-activation at least AMBIG_DEFAULT from zero exist (a ray has
+    16 evaluations x ~9e3 relu units)."""
+    if os.environ.get("PNYOLO_BWD_PRECISION") == "f32":
+        pytest.skip("the default backward is the split-f16 one")
+    ns, H, W, kc, kf, kfd, n = 2, 64, 64, 6, 4, 2, 24
+    net, sc = scene_pair(ns, H, W, L, 4, 5, 3, 2700 + L, lat_hw=(16, 16))
+    _, tgt = synth.scene_cameras(ns)
+    rs = np.random.RandomState(19)
+    nc = H * W
+    rays = orc.gen_rays(tgt[None], W, H, 0.9 * W, 0.3, 1.8)[0].reshape(-1, 8)
+    dr = dict(u_coarse=rs.rand(nc, kc).astype(np.float32), u_fine=rs.rand(nc, kf - kfd).astype(np.float32),
+              u_fine2=rs.rand(nc, kf - kfd).astype(np.float32), g_depth=rs.randn(nc, kfd).astype(np.float32))
+    keep = clean_rays(sc, rays, kc, kf, kfd, dr, n, chunk=256, ambig=AMBIG_DEFAULT)
+    rays, dr = rays[torch.from_numpy(keep)], {k: v[keep] for k, v in dr.items()}
+    gt = torch.from_numpy(rs.uniform(0, 1, size=(n, 3)).astype(np.float32))
+    ren = NeRFRenderer(n_coarse=kc, n_fine=kf, n_fine_depth=kfd, white_bkgd=True).train()
+    ren.draws = dr
+    out = ren(net, rays[None].to(DEV), want_weights=True)
+    assert net.last_launch_f16x2(), "the default training forward is the f16x2 kernel"
+    hip = {p: {k: v[0] for k, v in out[p].items()} for p in ("coarse", "fine")}
+    render_loss(hip, gt.to(DEV), with_depth).backward()
+    ref = orc.render(sc, rays, kc, kf, kfd, dr["u_coarse"], dr["u_fine"], dr["u_fine2"], dr["g_depth"])
+    assert maxabs(out["coarse"]["rgb"][0], ref["coarse"]["rgb"].detach()) < 1e-4
+    render_loss(ref, gt, with_depth).backward()
+    worst = compare_param_grads(net, sc)
+    print("default arithmetic, render backward, margin %.0e: worst gradient error %.2e of the tensor's max (60 tensors)"
+          % (AMBIG_DEFAULT, worst))
+
+
+def test_latent_gradient_super_batch_side_streams():
+    """SB = 3 scenes with a latent that requires grad, deferred weight gradients, scenes 1.. on side streams: every scene's
+    d loss / d latent against autograd through the oracle (the zero fill of the gradient buffer has to be ordered before the
+    side streams' atomics: render._RenderFunction.backward)."""
+    SB, ns, H, W, kc, kf, kfd, n = 3, 2, 32, 32, 16, 8, 4, 24
+    c = pconf.default_mv()
+    net = make_model(c["model"], stop_encoder_grad=True)
+    sd_c, sd_f = synth.mlp_state(3401), synth.mlp_state(3402)
+    net.mlp_coarse.load_state_dict({k: torch.from_numpy(v) for k, v in sd_c.items()})
+    net.mlp_fine.load_state_dict({k: torch.from_numpy(v) for k, v in sd_f.items()})
+    net = net.to(DEV).train()
+    lat = np.concatenate([synth.latent(3410 + i, ns, 512, H // 2, W // 2) for i in range(SB)])
+    poses = np.stack([synth.scene_cameras(ns, radius=1.3 + 0.1 * i)[0] for i in range(SB)])
+    focal = torch.tensor([[28.0, 28.0], [30.0, 31.0], [27.0, 29.0]])
+    lat_hip = torch.from_numpy(lat).to(DEV).requires_grad_()
+    net.encode(torch.zeros(SB, ns, 3, H, W), torch.from_numpy(poses), focal, latent=lat_hip)
+    mc = {k: torch.from_numpy(v).requires_grad_() for k, v in sd_c.items()}
+    mf = {k: torch.from_numpy(v).requires_grad_() for k, v in sd_f.items()}
+    rs = np.random.RandomState(14)
+    rays_l, dr_l, scs = [], [], []
+    for i in range(SB):
+        sc = orc.Scene(mc, mf, lat[i * ns:(i + 1) * ns], poses[i], focal[i:i + 1], None, W, H)
+        sc.mlp_coarse, sc.mlp_fine = mc, mf
+        sc.latent = torch.from_numpy(lat[i * ns:(i + 1) * ns].copy()).requires_grad_()
+        cand = orc.gen_rays(synth.pose_spherical(100.0 + 25 * i, -20.0, 1.3)[None], W, H, 29.0, 0.3, 1.8)[0].reshape(-1, 8)
+        nc = cand.shape[0]
+        dr = dict(u_coarse=rs.rand(nc, kc).astype(np.float32), u_fine=rs.rand(nc, kf - kfd).astype(np.float32),
+                  u_fine2=rs.rand(nc, kf - kfd).astype(np.float32), g_depth=rs.randn(nc, kfd).astype(np.float32))
+        keep = clean_rays(sc, cand, kc, kf, kfd, dr, n)
+        rays_l.append(cand[torch.from_numpy(keep)])
+        dr_l.append({k: v[keep] for k, v in dr.items()})
+        scs.append(sc)
+    rays = torch.stack(rays_l)
+    gt = torch.from_numpy(rs.uniform(0, 1, size=(SB, n, 3)).astype(np.float32))
+    ren = NeRFRenderer(n_coarse=kc, n_fine=kf, n_fine_depth=kfd, white_bkgd=True).train()
+    ren.draws = {k: np.concatenate([d[k] for d in dr_l]) for k in dr_l[0]}
+    out = ren(net, rays.to(DEV), want_weights=True)
+    loss = torch.nn.functional.mse_loss(out["coarse"]["rgb"], gt.to(DEV)) + torch.nn.functional.mse_loss(out["fine"]["rgb"], gt.to(DEV))
+    loss.backward()
+    ref_c, ref_f = [], []
+    for i in range(SB):
+        r = orc.render(scs[i], rays[i], kc, kf, kfd, dr_l[i]["u_coarse"], dr_l[i]["u_fine"], dr_l[i]["u_fine2"], dr_l[i]["g_depth"])
+        ref_c.append(r["coarse"]["rgb"])
+        ref_f.append(r["fine"]["rgb"])
+    ref_loss = torch.nn.functional.mse_loss(torch.stack(ref_c), gt) + torch.nn.functional.mse_loss(torch.stack(ref_f), gt)
+    ref_loss.backward()
+    assert lat_hip.grad is not None and lat_hip.grad.shape == lat_hip.shape
+    for i in range(SB):
+        assert float(scs[i].latent.grad.abs().max()) > 0.0
+        grad_check("d latent, scene %d" % i, lat_hip.grad[i * ns:(i + 1) * ns], scs[i].latent.grad)
+    compare_param_grads(net, scs[0])
