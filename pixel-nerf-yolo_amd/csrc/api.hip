@@ -107,6 +107,25 @@ static void pack_layer_h2(const float* W, int n_out, int k_in, int k_pad, std::v
                     }
 }
 
+// The same split for mlp_h2w.hip (v_mfma_f32_16x16x32_f16): per 32-k step [n-tile of 16][plane][lane] x 8 halves, lane l holding
+// W[16 nt + (l & 15)][32 j + 8 (l >> 4) + 0..7].
+static void pack_layer_h3(const float* W, int n_out, int k_in, int k_pad, std::vector<float>& dst) {
+    const int J = k_pad / 32, NT = n_out / 16;
+    const size_t base = dst.size();
+    dst.resize(base + (size_t)J * NT * 2 * 64 * 4);
+    _Float16* o = reinterpret_cast<_Float16*>(dst.data() + base);
+    for (int j = 0; j < J; ++j)
+        for (int nt = 0; nt < NT; ++nt)
+            for (int p = 0; p < 2; ++p)
+                for (int l = 0; l < 64; ++l)
+                    for (int r = 0; r < 8; ++r) {
+                        const int n = 16 * nt + (l & 15), k = 32 * j + 8 * (l >> 4) + r;
+                        const float w = (k < k_in) ? W[(size_t)n * k_in + k] : 0.0f;
+                        const _Float16 w1 = (_Float16)w;
+                        *o++ = p == 0 ? w1 : (_Float16)(w - (float)w1);
+                    }
+}
+
 static const HostTensor* find(const pny_model* m, const std::string& name) {
     auto it = m->host.find(name);
     return it == m->host.end() ? nullptr : &it->second;
@@ -213,6 +232,21 @@ static int pack_mlp(pny_model* m, const std::string& pre, MlpWeights& w, MlpWeig
         m->repack.push_back({PACK_H2, name, "", off, nullptr, HID, k_in, k_pad, 0});
         return 0;
     };
+    auto packed_h3 = [&](const std::string& name, int k_in, int k_pad, const float** slot) -> int {
+        if ((rc = need(m, name, {HID, k_in}, &t))) return rc;
+        while (plan.blob.size() % 16) plan.blob.push_back(0.f);
+        const size_t off = plan.blob.size();
+        pack_layer_h3(t->data.data(), HID, k_in, k_pad, plan.blob);
+        plan.fix.push_back({slot, off});
+        m->repack.push_back({PACK_H3, name, "", off, nullptr, HID, k_in, k_pad, 0});
+        return 0;
+    };
+    if ((rc = packed_h3(pre + "lin_in.weight", d_in, D_IN_PAD, &wt.h3_in))) return rc;
+    for (int b = 0; b < d.n_blocks; ++b) {
+        const std::string p = pre + "blocks." + std::to_string(b);
+        if ((rc = packed_h3(p + ".fc_0.weight", HID, HID, &wt.h3_fc0[b]))) return rc;
+        if ((rc = packed_h3(p + ".fc_1.weight", HID, HID, &wt.h3_fc1[b]))) return rc;
+    }
     if ((rc = packed_h2(pre + "lin_in.weight", d_in, D_IN_PAD, &wt.h2_in))) return rc;
     for (int b = 0; b < d.n_blocks; ++b) {
         const std::string p = pre + "blocks." + std::to_string(b);
@@ -443,7 +477,7 @@ int pny_model_refresh(pny_model* m, pny_stream stream) {
             j.n_out = e.n_out;
             j.k_in = e.k_in;
             j.k_pad = e.k_pad;
-            if (e.kind == PACK_A || e.kind == PACK_NT || e.kind == PACK_H2)
+            if (e.kind == PACK_A || e.kind == PACK_NT || e.kind == PACK_H2 || e.kind == PACK_H3)
                 j.count = (e.n_out / 32) * (e.k_pad / 8) * 64;       // 16-byte elements
             else if (e.kind == PACK_AT || e.kind == PACK_H2T)
                 j.count = (e.k_in / 32) * (e.k_pad / 8) * 64;
@@ -845,9 +879,12 @@ int fill_mlp_args(pny_scene* s, int mode, const float* xyz, const float* dirs, c
     {
         const MlpWeightsT& wt = fine_w ? s->m->fine_t : s->m->coarse_t;
         a.h2_in = wt.h2_in;
+        a.h3_in = wt.h3_in;
         for (int b = 0; b < d.n_blocks; ++b) {
             a.h2_fc0[b] = wt.h2_fc0[b];
             a.h2_fc1[b] = wt.h2_fc1[b];
+            a.h3_fc0[b] = wt.h3_fc0[b];
+            a.h3_fc1[b] = wt.h3_fc1[b];
         }
     }
     a.w_base = s->m->packed.f();
@@ -892,6 +929,8 @@ int fill_mlp_args(pny_scene* s, int mode, const float* xyz, const float* dirs, c
     return 0;
 }
 }  // namespace pny
+
+static bool h2w_default() { return false; }   // (experimental until it wins: PNYOLO_H2_WIDE=1)
 
 static int run_mlp(pny_scene* s, int mode, const float* xyz, const float* dirs, const float* rays, const float* z,
                    int K, long long n_points, int coarse, float* out, hipStream_t st, int stash_pass = -1) {
@@ -972,6 +1011,10 @@ static int run_mlp(pny_scene* s, int mode, const float* xyz, const float* dirs, 
     bool use_h2s = use_h2 && n_points <= 32ll * mlp_max_grid(MLP_8x64);
     if (use_h2)
         if (const char* e = getenv("PNYOLO_H2_SPLIT")) use_h2s = atoi(e) != 0;
+    // wide shape (mlp_h2w.hip: 4 waves x 512 registers, 16 x 16 x 32 MFMAs): launches that give every CU more than one tile
+    bool use_h2w = use_h2 && !use_h2s && mlp_h2w_supports(d.n_blocks, d.combine_layer) && h2w_default();
+    if (use_h2 && !use_h2s)
+        if (const char* e = getenv("PNYOLO_H2_WIDE")) use_h2w = atoi(e) != 0 && mlp_h2w_supports(d.n_blocks, d.combine_layer);
     const int tm = use_h2s ? 32 : mlp_tile_samples(variant);
     const long long tiles = (n_points + tm - 1) / tm;
     if (tiles > 0x7fffffffll) return fail(PNY_ERR_ARG, "too many points for one launch");
@@ -993,6 +1036,8 @@ static int run_mlp(pny_scene* s, int mode, const float* xyz, const float* dirs, 
     }
     if (use_h2s)
         launch_mlp_h2s(a, grid, st);
+    else if (use_h2w)
+        launch_mlp_h2w(a, grid, st);
     else if (use_h2)
         launch_mlp_h2(a, grid, st);
     else

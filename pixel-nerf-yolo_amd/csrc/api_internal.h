@@ -103,6 +103,9 @@ struct MlpWeightsT {
     const float* h2_in;       // split-f16 images (mlp_h2.hip)
     const float* h2_fc0[MAX_BLOCKS];
     const float* h2_fc1[MAX_BLOCKS];
+    const float* h3_in;       // split-f16 images in the 16 x 16 x 32 MFMA's operand order (mlp_h2w.hip)
+    const float* h3_fc0[MAX_BLOCKS];
+    const float* h3_fc1[MAX_BLOCKS];
     const float* h2T_out;     // split-f16 images of the transposed matrices (mlp_bwd_h2.hip)
     const float* h2T_fc0[MAX_BLOCKS];
     const float* h2T_fc1[MAX_BLOCKS];

@@ -1,0 +1,451 @@
+// The WIDE shape of the fused conditioned-MLP kernel on split-f16 operands (gfx950, MI355X): 4 waves x 512 registers, one wave
+// per SIMD, v_mfma_f32_16x16x32_f16.
+//
+// Same function, same LDS activation image and the same three products per fp32 multiply as mlp_h2.hip (x1 w1 + x2 w1 + x1 w2,
+// fp32 accumulation) -- what changes is who holds what:
+//   * a workgroup is 4 waves; wave w owns features [128 w, 128 w + 128) of the 64 samples of the tile: 8 x 4 accumulator tiles
+//     of 16 x 16 (128 registers for the residual stream h, 128 for net; the register file of a SIMD belongs to ONE wave);
+//   * a B fragment read from LDS serves 8 n-tiles instead of 4: half the LDS read traffic per MFMA;
+//   * v_mfma_f32_16x16x32_f16: the accumulator tile of a lane is ONE feature quad of ONE sample, so the 8-byte plane slots an
+//     epilogue writes are 256 contiguous bytes per 16 lanes -- no bank conflict (the 32 x 32 layout's are 2-way) -- and the chip
+//     holds a higher clock on this MFMA shape (MI355X_MICROARCH.md, DVFS give-back 7; measured here: profiles/r03_*);
+//   * weights: one stream per wave, [32-k step][n-tile of 16][plane][lane] x 16 bytes (api.hip pack_layer_h3); a step's 16
+//     fragments are consumed n-tile by n-tile (12 MFMAs each) and every fragment is refetched for the NEXT step right behind
+//     its last use -- 7/8 of a step (1300 cycles) of latency cover with 64 registers and no separate ring.
+// Render only (no STASH instantiation).  PNYOLO_H2_WIDE=1 selects it for full-size projected launches (api.hip run_mlp).
+#include <cstdlib>
+#include <cstring>
+#include <cstdio>
+#include <vector>
+
+#include "mlp_h2_core.h"
+
+namespace pny {
+
+typedef float f32x4a __attribute__((ext_vector_type(4)));
+
+namespace hw {
+constexpr int NW = 4, THREADS = 64 * NW, TM = 64;
+constexpr int NT = 8, MT = 4;                 // 16 x 16 accumulator tiles per wave: 128 features x 64 samples
+constexpr int ROW_BYTES = TM * 16;            // one plane of one row (8 features x TM samples x f16)
+constexpr int ACT_BYTES = 64 * 2 * ROW_BYTES; // [row = feature / 8][plane][sample] x 16 bytes = 128 KiB
+constexpr int TAP_BYTES = 32 * TM;
+constexpr int MAX_NB = 6;
+__host__ __device__ constexpr int lds_bytes(int n_blocks) { return ACT_BYTES + TAP_BYTES + (1 + 2 * n_blocks) * HID * 4; }
+}  // namespace hw
+
+struct HwSeg {
+    unsigned off;  // byte offset of fragment (step 0, this wave's first n-tile, plane 0) in the weight blob
+    int jn;        // 32-k steps (even)
+};
+__device__ __forceinline__ HwSeg hwseg(const WStream& ws, const float* packed, int jn, int wave) {
+    HwSeg s;
+    s.off = (unsigned)(reinterpret_cast<const char*>(packed) - ws.base) + (unsigned)((hw::NT * wave) * 2 * 64) * 16u;
+    s.jn = jn;
+    return s;
+}
+// fragment (step j, local n-tile nt, plane p): this lane's 8 halves W[16 nt_g + (l & 15)][32 j + 8 (l >> 4) + 0..7]
+__device__ __forceinline__ h8 hwload(const WStream& ws, unsigned seg_off, int nt, int p, int j) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.lane_off, seg_off + (unsigned)(((j * 32 + nt) * 2 + p) * 64) * 16u, 0);
+    return __builtin_bit_cast(h8, v);
+}
+struct HwRing {
+    h8 f[hw::NT][2];   // the fragments of the step about to be consumed
+};
+__device__ __forceinline__ void hwring_fill(HwRing& r, const WStream& ws, const HwSeg& s) {
+#pragma unroll
+    for (int nt = 0; nt < hw::NT; ++nt)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) r.f[nt][p] = hwload(ws, s.off, nt, p, 0);
+}
+
+template <class Acc>
+__device__ __forceinline__ void hwzero(Acc (&t)[hw::NT][hw::MT]) {
+#pragma unroll
+    for (int nt = 0; nt < hw::NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < hw::MT; ++mt) t[nt][mt] = f32x4a{0.f, 0.f, 0.f, 0.f};
+}
+
+// One 32-k step: B = the step's activation fragments (4 m-tiles x 2 planes), Bn receives the next step's (read from `bnext`).
+// n-tile by n-tile: 12 MFMAs on the n-tile's two weight fragments, which are then refetched for the next step.
+__device__ __forceinline__ void hwstep(f32x4a (&acc)[hw::NT][hw::MT], HwRing& r, const h8 (&B)[hw::MT][2], h8 (&Bn)[hw::MT][2],
+                                       const char* bnext, const WStream& ws, unsigned src, int jx) {
+    using namespace hw;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(r.f[nt][0], B[mt][0], acc[nt][mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(r.f[nt][0], B[mt][1], acc[nt][mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(r.f[nt][1], B[mt][0], acc[nt][mt], 0, 0, 0);
+        // one of the next step's 8 activation fragments per n-tile group
+        Bn[nt >> 1][nt & 1] = *reinterpret_cast<const h8*>(bnext + (nt & 1) * ROW_BYTES + (nt >> 1) * 256);
+        r.f[nt][0] = hwload(ws, src, nt, 0, jx);
+        r.f[nt][1] = hwload(ws, src, nt, 1, jx);
+#ifndef PNY_H2_NOSCHED
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+#endif
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// acc += W_slice . act over segment `cur`; leaves the ring holding step 0 of `next`
+__device__ __forceinline__ void hwgemm(f32x4a (&acc)[hw::NT][hw::MT], HwRing& r, const WStream& ws, const HwSeg& cur, const HwSeg& next,
+                                       const char* planes, int lane) {
+    using namespace hw;
+    const char* bp = planes + (lane >> 4) * (2 * ROW_BYTES) + (lane & 15) * 16;   // row 4 j + (lane >> 4), plane 0, sample lane & 15
+    const int jn = cur.jn;
+    h8 B0[MT][2], B1[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) B0[mt][p] = *reinterpret_cast<const h8*>(bp + p * ROW_BYTES + mt * 256);
+    for (int j = 0; j < jn; j += 2) {
+        hwstep(acc, r, B0, B1, bp + (j + 1) * (8 * ROW_BYTES), ws, cur.off, j + 1);
+        const bool last = j + 2 >= jn;
+        hwstep(acc, r, B1, B0, bp + (last ? j + 1 : j + 2) * (8 * ROW_BYTES), ws, last ? next.off : cur.off, last ? 0 : j + 2);
+    }
+}
+
+// Block entry / GEMM epilogue (mlp_h2.hip h2epilogue for the 16 x 16 accumulator layout): acc += bias (+ the staged fp32
+// projection, ADDZ), then the planes of relu(acc) go to the slots of the lane's own feature quads.
+// accumulator tile (nt, mt) of lane l = features 128 w + 16 nt + 4 (l >> 4) + 0..3 of sample 16 mt + (l & 15):
+// row 16 w + 2 nt + (l >> 5), half (l >> 4) & 1.
+template <bool ADDZ>
+__device__ __forceinline__ void hwepilogue(f32x4a (&acc)[hw::NT][hw::MT], const float* bias, char* planes, int wave, int lane,
+                                           unsigned* range_flag) {
+    using namespace hw;
+    const int fq = lane >> 4;
+    const float* bl = bias + 128 * wave + 4 * fq;
+    char* base = planes + (16 * wave + (fq >> 1)) * (2 * ROW_BYTES) + (lane & 15) * 16 + 8 * (fq & 1);
+    float rmax = 0.f;   // f16-range guard (include/pnyolo.h pny_model_range_status)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const float4 b = *reinterpret_cast<const float4*>(bl + 16 * nt);
+        float2 za[MT], zb[MT];
+        if (ADDZ) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const char* s0 = base + (2 * nt) * (2 * ROW_BYTES) + mt * 256;
+                za[mt] = *reinterpret_cast<const float2*>(s0);
+                zb[mt] = *reinterpret_cast<const float2*>(s0 + ROW_BYTES);
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            char* s0 = base + (2 * nt) * (2 * ROW_BYTES) + mt * 256;
+            float x0 = acc[nt][mt][0] + b.x, x1 = acc[nt][mt][1] + b.y, x2 = acc[nt][mt][2] + b.z, x3 = acc[nt][mt][3] + b.w;
+            if (ADDZ) {
+                x0 += za[mt].x;
+                x1 += za[mt].y;
+                x2 += zb[mt].x;
+                x3 += zb[mt].y;
+            }
+            acc[nt][mt] = f32x4a{x0, x1, x2, x3};
+            const float r0 = relu1(x0), r1 = relu1(x1), r2 = relu1(x2), r3 = relu1(x3);
+            rmax = fmaxf(fmaxf(rmax, fmaxf(r0, r1)), fmaxf(r2, r3));
+            h4 p0, p1;
+            split4(r0, r1, r2, r3, p0, p1);
+            *reinterpret_cast<h4*>(s0) = p0;
+            *reinterpret_cast<h4*>(s0 + ROW_BYTES) = p1;
+        }
+    }
+    if (__builtin_expect(!(rmax < 65520.0f), 0)) range_report(range_flag, 1u);
+}
+
+// Cross-view running sum slab of the workgroup: tile t = nt * MT + mt of lane l at float4 index (wave * 32 + t) * 64 + l
+struct HwSlab {
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned lane_off;
+};
+__device__ __forceinline__ void hwslab_store(const f32x4a (&h)[hw::NT][hw::MT], const HwSlab& sl) {
+    using namespace hw;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h[nt][mt]), sl.rsrc, sl.lane_off + (unsigned)((nt * MT + mt) * 64 * 16), 0, 2);
+}
+__device__ __forceinline__ void hwslab_load(f32x4a (&t)[hw::NT][hw::MT], const HwSlab& sl) {
+    using namespace hw;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            t[nt][mt] = __builtin_bit_cast(f32x4a, __builtin_amdgcn_raw_buffer_load_b128(sl.rsrc, sl.lane_off, (unsigned)((nt * MT + mt) * 64 * 16), 2));
+}
+
+// Bilinear gather of the projected maps, staged in fp32 in the plane slots (see mlp_h2.hip h2gather_commit): a wave pass covers
+// 8 samples x one 128-byte line (32 channels); a lane serves TWO samples (sample blocks 2 w and 2 w + 1), whose taps it re-reads
+// from the tap table at every block (24 registers that would otherwise stay live across the GEMMs), and moves one line of
+// both per piece: 8 tap loads of 16 bytes = 32 registers, pieces in flight as the caller chooses.
+struct HwTaps {
+    const float* t[2][4];
+    float w[2][4];
+};
+__device__ __forceinline__ void hwgather_setup(HwTaps& g, const float* view_base, const float4* tap_tab, int wave, int lane) {
+    const float* base = view_base + 4 * (lane >> 3);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = (2 * wave + i) * 8 + (lane & 7);
+        const float4 o = tap_tab[2 * m], w = tap_tab[2 * m + 1];
+        g.t[i][0] = base + __float_as_int(o.x);
+        g.t[i][1] = base + __float_as_int(o.y);
+        g.t[i][2] = base + __float_as_int(o.z);
+        g.t[i][3] = base + __float_as_int(o.w);
+        g.w[i][0] = w.x;
+        g.w[i][1] = w.y;
+        g.w[i][2] = w.z;
+        g.w[i][3] = w.w;
+    }
+}
+struct HwPiece {
+    float4 x[2][4];   // [sample][tap]
+};
+__device__ __forceinline__ void hwgather_issue(HwPiece& pc, const HwTaps& g, int c0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pc.x[i][k] = *reinterpret_cast<const float4*>(g.t[i][k] + c0);
+}
+// piece ln of the block (channels [32 ln, 32 ln + 32)): feature quad 8 ln + (lane >> 3) -> row 4 ln + (lane >> 4)
+__device__ __forceinline__ void hwgather_commit(const HwPiece& pc, const HwTaps& g, char* planes, int ln, int wave, int lane) {
+    using namespace hw;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = (2 * wave + i) * 8 + (lane & 7);
+        const float4(&x)[4] = pc.x[i];
+        const float(&w)[4] = g.w[i];
+        float2 lo, hi;
+        lo.x = __builtin_fmaf(x[3].x, w[3], __builtin_fmaf(x[2].x, w[2], __builtin_fmaf(x[1].x, w[1], x[0].x * w[0])));
+        lo.y = __builtin_fmaf(x[3].y, w[3], __builtin_fmaf(x[2].y, w[2], __builtin_fmaf(x[1].y, w[1], x[0].y * w[0])));
+        hi.x = __builtin_fmaf(x[3].z, w[3], __builtin_fmaf(x[2].z, w[2], __builtin_fmaf(x[1].z, w[1], x[0].z * w[0])));
+        hi.y = __builtin_fmaf(x[3].w, w[3], __builtin_fmaf(x[2].w, w[2], __builtin_fmaf(x[1].w, w[1], x[0].w * w[0])));
+        char* s0 = planes + (4 * ln + (lane >> 4)) * (2 * ROW_BYTES) + m * 16 + 8 * ((lane >> 3) & 1);
+        *reinterpret_cast<float2*>(s0) = lo;
+        *reinterpret_cast<float2*>(s0 + ROW_BYTES) = hi;
+    }
+}
+
+// per (view, tile) prologue (mlp_h2.hip h2prologue for 256 threads): lin_in's B operand as f16 planes in rows 0..7, tap table
+__device__ __forceinline__ void hwprologue(const MlpArgs& a, int v, long long tile, char* planes, float4* tap_tab, int tid) {
+    using namespace hw;
+    constexpr int NPART = THREADS / TM;
+    const int m = tid % TM, part = tid / TM;
+    long long s = tile * TM + m;
+    if (s >= a.n_points) s = a.n_points - 1;
+    float p[3], d[3];
+    load_point(a, s, p, d);
+    const Cam cam = a.cams[v];
+    float xr[3], xc[3], vd[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        xr[i] = cam.w2c[4 * i + 0] * p[0] + cam.w2c[4 * i + 1] * p[1] + cam.w2c[4 * i + 2] * p[2];
+        xc[i] = xr[i] + cam.w2c[4 * i + 3];
+        vd[i] = cam.w2c[4 * i + 0] * d[0] + cam.w2c[4 * i + 1] * d[1] + cam.w2c[4 * i + 2] * d[2];
+    }
+    float rmax = 0.f;
+    for (int g = part; g < D_IN_PAD / 4; g += NPART) {
+        h4 p0, p1;
+        const float e0 = input_entry(4 * g + 0, xr, vd, a.freq_factor, a.num_freqs), e1 = input_entry(4 * g + 1, xr, vd, a.freq_factor, a.num_freqs);
+        const float e2 = input_entry(4 * g + 2, xr, vd, a.freq_factor, a.num_freqs), e3 = input_entry(4 * g + 3, xr, vd, a.freq_factor, a.num_freqs);
+        rmax = fmaxf(fmaxf(rmax, fmaxf(fabsf(e0), fabsf(e1))), fmaxf(fabsf(e2), fabsf(e3)));
+        split4(e0, e1, e2, e3, p0, p1);
+        char* s0 = planes + (g >> 1) * (2 * ROW_BYTES) + m * 16 + 8 * (g & 1);
+        *reinterpret_cast<h4*>(s0) = p0;
+        *reinterpret_cast<h4*>(s0 + ROW_BYTES) = p1;
+    }
+    if (__builtin_expect(!(rmax < 65520.0f), 0)) range_report(a.range_flag, 1u);
+    if (part == NPART - 1) {
+        float ux, uy;
+        if (!a.yolo) {
+            ux = -xc[0] / xc[2];
+            uy = -xc[1] / xc[2];
+        } else {
+            ux = xc[0] / xc[2];
+            uy = xc[1] / xc[2];
+        }
+        ux = ux * cam.fx + cam.cx;
+        uy = uy * cam.fy + cam.cy;
+        const float gx = ux * a.sx - 1.0f, gy = uy * a.sy - 1.0f;
+        const float ix = ((gx + 1.0f) / 2.0f) * (float)(a.Wl - 1);
+        const float iy = ((gy + 1.0f) / 2.0f) * (float)(a.Hl - 1);
+        const float x0 = floorf(ix), y0 = floorf(iy);
+        const float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
+        float wgt[4] = {(x1 - ix) * (y1 - iy), (ix - x0) * (y1 - iy), (x1 - ix) * (iy - y0), (ix - x0) * (iy - y0)};
+        const float xs[4] = {x0, x1, x0, x1};
+        const float ys[4] = {y0, y0, y1, y1};
+        const bool cull = a.yolo && !(xc[2] < 0.0f);
+        int offs[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool ok = (xs[k] >= 0.f) && (xs[k] <= (float)(a.Wl - 1)) && (ys[k] >= 0.f) && (ys[k] <= (float)(a.Hl - 1));
+            offs[k] = 0;
+            if (ok)
+                offs[k] = ((int)ys[k] * a.Wl + (int)xs[k]) * a.tap_stride;
+            else
+                wgt[k] = wgt[k] * 0.0f;
+            if (cull || (a.yolo && (wgt[k] != wgt[k]))) wgt[k] = 0.0f;
+        }
+        tap_tab[2 * m] = make_float4(__int_as_float(offs[0]), __int_as_float(offs[1]), __int_as_float(offs[2]), __int_as_float(offs[3]));
+        tap_tab[2 * m + 1] = make_float4(wgt[0], wgt[1], wgt[2], wgt[3]);
+    }
+}
+
+__global__ __launch_bounds__(hw::THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void pny_mlp_h2w_kernel(const MlpArgs a) {
+    using namespace hw;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    char* planes = smem_raw;
+    float4* tap_tab = reinterpret_cast<float4*>(smem_raw + ACT_BYTES);
+    float* bias_tab = reinterpret_cast<float*>(smem_raw + ACT_BYTES + TAP_BYTES);   // [b_in, b_fc0[0], b_fc1[0], b_fc0[1], ...][512]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const HwSlab slab = {__builtin_amdgcn_make_buffer_rsrc(a.scratch + (size_t)blockIdx.x * (TM * HID), 0, TM * HID * 4, 0x00020000),
+                         (unsigned)((wave * (NT * MT * 64) + lane) * 16)};
+    const int nb = a.n_blocks;
+    const int nvb = a.combine_layer < nb ? a.combine_layer : nb;
+    const WStream ws = wstream(a, lane);
+    const HwSeg s_in = hwseg(ws, a.h3_in, D_IN_PAD / 32, wave);
+    auto fc0seg = [&](int b) { return hwseg(ws, a.h3_fc0[b], HID / 32, wave); };
+    auto fc1seg = [&](int b) { return hwseg(ws, a.h3_fc1[b], HID / 32, wave); };
+    auto entry_bias = [&](int b) -> const float* { return bias_tab + (b == 0 ? 0 : 2 * b) * HID; };
+    auto fc0_bias = [&](int b) -> const float* { return bias_tab + (1 + 2 * b) * HID; };
+    HwRing ring;
+    hwring_fill(ring, ws, s_in);
+    for (int i = tid; i < (1 + 2 * nb) * HID; i += THREADS) {
+        const int vec = i / HID, f = i % HID;
+        const float* src = vec == 0 ? a.w.b_in : ((vec & 1) ? a.w.b_fc0[(vec - 1) >> 1] : a.w.b_fc1[(vec - 2) >> 1]);
+        bias_tab[i] = src[f];
+    }
+
+    const bool xcd_order = (gridDim.x & 7) == 0;   // see mlp.hip
+    const long long t_chunk = xcd_order ? (a.n_tiles + 7) / 8 : a.n_tiles;
+    const long long t_first = xcd_order ? (long long)(blockIdx.x & 7) * t_chunk + (blockIdx.x >> 3) : blockIdx.x;
+    const long long t_last = xcd_order ? ((long long)((blockIdx.x & 7) + 1) * t_chunk < a.n_tiles
+                                              ? (long long)((blockIdx.x & 7) + 1) * t_chunk : (long long)a.n_tiles)
+                                       : (long long)a.n_tiles;
+    const int t_step = xcd_order ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    for (long long tile = t_first; tile < t_last; tile += t_step) {
+        f32x4a h[NT][MT];
+        f32x4a net[NT][MT];
+        // one residual block from "planes hold relu(h_in)" on: net = fc_0(.), h += fc_1(relu(net + b_fc0))
+        auto block_tail = [&](int blk, const HwSeg& after, bool slab_in) {
+            hwzero(net);
+            __syncthreads();
+            hwgemm(net, ring, ws, fc0seg(blk), fc1seg(blk), planes, lane);
+            __syncthreads();
+            hwepilogue<false>(net, fc0_bias(blk), planes, wave, lane, a.range_flag);
+            if (slab_in) {
+                hwslab_load(net, slab);   // the other views' running sum, in the registers of the now dead `net`
+                __syncthreads();
+                hwgemm(h, ring, ws, fc1seg(blk), after, planes, lane);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) h[nt][mt] = net[nt][mt] + h[nt][mt];
+            } else {
+                __syncthreads();
+                hwgemm(h, ring, ws, fc1seg(blk), after, planes, lane);
+            }
+        };
+        for (int v = 0; v < a.NS; ++v) {
+            const HwSeg after_view = v + 1 < a.NS ? s_in : (nvb < nb ? fc0seg(nvb) : s_in);
+            __syncthreads();
+            hwprologue(a, v, tile, planes, tap_tab, tid);
+            hwzero(h);
+            __syncthreads();
+            hwgemm(h, ring, ws, s_in, fc0seg(0), planes, lane);
+            for (int blk = 0; blk < nvb; ++blk) {
+                // h += interp(lin_z[blk](latent map)): the block's 512 projected channels in 16 pieces of 32 (one 128-byte line
+                // per tap and sample), four in flight
+                const int cb = blk * HID;
+                HwTaps g;
+                HwPiece pc[4];
+                __syncthreads();  // every wave is done reading the planes (previous GEMM)
+                hwgather_setup(g, a.zp + (size_t)v * a.Hl * a.Wl * a.zp_stride, tap_tab, wave, lane);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) hwgather_issue(pc[i], g, cb + 32 * i);
+#pragma unroll
+                for (int ln = 0; ln < 16; ++ln) {
+                    if (ln + 3 < 16) hwgather_issue(pc[(ln + 3) & 3], g, cb + 32 * (ln + 3));
+                    __builtin_amdgcn_sched_barrier(0);
+                    hwgather_commit(pc[ln & 3], g, planes, ln, wave, lane);
+                }
+                __syncthreads();  // projection visible
+                hwepilogue<true>(h, entry_bias(blk), planes, wave, lane, a.range_flag);
+                const bool last = blk + 1 == nvb;
+                block_tail(blk, last ? after_view : fc0seg(blk + 1), last && v > 0);
+            }
+            if (a.NS > 1) {
+                if (v + 1 < a.NS) {
+                    hwslab_store(h, slab);
+                } else {
+                    const float rns = 1.0f / (float)a.NS;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) h[nt][mt] = h[nt][mt] * rns;
+                }
+            }
+        }
+        for (int blk = nvb; blk < nb; ++blk) {
+            __syncthreads();
+            hwepilogue<false>(h, entry_bias(blk), planes, wave, lane, a.range_flag);
+            block_tail(blk, blk + 1 < nb ? fc0seg(blk + 1) : s_in, false);
+        }
+        // out = lin_out(relu(h + b_fc1[last])) (reference resnetfc.py:185) + output head (models.py:312-317)
+        __syncthreads();
+        hwepilogue<false>(h, entry_bias(nb), planes, wave, lane, a.range_flag);
+        __syncthreads();
+        for (int idx = tid; idx < a.d_out * TM; idx += THREADS) {
+            const int o = idx / TM, m = idx % TM;
+            const float4* wrow = reinterpret_cast<const float4*>(a.w.w_out + (size_t)o * HID);
+            float sum = 0.f;
+#pragma unroll 4
+            for (int kg = 0; kg < HID / 8; ++kg) {
+                const h8 x0 = *reinterpret_cast<const h8*>(planes + kg * (2 * ROW_BYTES) + m * 16);
+                const h8 x1 = *reinterpret_cast<const h8*>(planes + kg * (2 * ROW_BYTES) + ROW_BYTES + m * 16);
+                const float4 wa = wrow[2 * kg], wb = wrow[2 * kg + 1];
+                sum += ((float)x0[0] + (float)x1[0]) * wa.x;
+                sum += ((float)x0[1] + (float)x1[1]) * wa.y;
+                sum += ((float)x0[2] + (float)x1[2]) * wa.z;
+                sum += ((float)x0[3] + (float)x1[3]) * wa.w;
+                sum += ((float)x0[4] + (float)x1[4]) * wb.x;
+                sum += ((float)x0[5] + (float)x1[5]) * wb.y;
+                sum += ((float)x0[6] + (float)x1[6]) * wb.z;
+                sum += ((float)x0[7] + (float)x1[7]) * wb.w;
+            }
+            sum += a.w.b_out[o];
+            if (!a.yolo) {
+                if (o < 3)
+                    sum = 1.0f / (1.0f + expf(-sum));
+                else if (o == 3)
+                    sum = fmaxf(sum, 0.f);
+            }
+            const long long s = tile * TM + m;
+            if (s < a.n_points) a.out[s * a.d_out + o] = sum;
+        }
+    }
+}
+
+bool mlp_h2w_supports(int n_blocks, int combine_layer) { return n_blocks <= hw::MAX_NB && combine_layer >= 1; }
+
+void launch_mlp_h2w(const MlpArgs& a, int grid, hipStream_t st) {
+    static bool attr_set[64] = {};
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    dev_ &= 63;
+    if (!attr_set[dev_]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pny_mlp_h2w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  hw::lds_bytes(hw::MAX_NB));
+        attr_set[dev_] = true;
+    }
+    hipLaunchKernelGGL(pny_mlp_h2w_kernel, dim3(grid), dim3(hw::THREADS), hw::lds_bytes(a.n_blocks), st, a);
+}
+
+}  // namespace pny

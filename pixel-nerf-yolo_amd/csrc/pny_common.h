@@ -89,6 +89,10 @@ struct MlpArgs {
     const float* h2_in;
     const float* h2_fc0[MAX_BLOCKS];
     const float* h2_fc1[MAX_BLOCKS];
+    // the same layers in the 16 x 16 x 32 MFMA's operand order (mlp_h2w.hip; api.hip pack_layer_h3)
+    const float* h3_in;
+    const float* h3_fc0[MAX_BLOCKS];
+    const float* h3_fc1[MAX_BLOCKS];
     // f16-range guard (include/pnyolo.h pny_model_range_status): host-visible word the f16x2 kernels OR PNY_RANGE_* bits into
     unsigned* range_flag;
     // Source-view cameras travel in the kernel-argument segment (NS entries used; 64 B each): a launch carries its own
@@ -97,7 +101,7 @@ struct MlpArgs {
 };
 
 // ---- device-side weight repack (pack.hip): the packed operand layouts rebuilt from the live parameter tensors
-enum { PACK_A = 0, PACK_AT = 1, PACK_NT = 2, PACK_COPY = 3, PACK_ADD2 = 4, PACK_H2 = 5, PACK_NTT = 6, PACK_H2T = 7 };
+enum { PACK_A = 0, PACK_AT = 1, PACK_NT = 2, PACK_COPY = 3, PACK_ADD2 = 4, PACK_H2 = 5, PACK_NTT = 6, PACK_H2T = 7, PACK_H3 = 8 };
 struct PackJob {
     const float* src;
     const float* src2;
@@ -199,6 +203,8 @@ bool mlp_h2_supports(int n_blocks, int combine_layer);
 void launch_mlp_h2(const MlpArgs& a, int grid, hipStream_t st);
 void launch_mlp_h2s(const MlpArgs& a, int grid, hipStream_t st);   // mlp_h2s.hip: a.n_tiles in 32-sample tiles, grid <= 2 x CUs
 void launch_mlp_h2_stash(const MlpArgs& a, int grid, hipStream_t st);   // + the backward's operand stash (a.stash_x, a.lay)     // 8x64 shape, projected latent, split-f16 operands (mlp_h2.hip)
+bool mlp_h2w_supports(int n_blocks, int combine_layer);
+void launch_mlp_h2w(const MlpArgs& a, int grid, hipStream_t st);   // mlp_h2w.hip: 4 waves x 512 registers, needs a.h3_*; 64-sample tiles
 int mlp_max_grid(int variant);      // resident workgroups = persistent grid size
 int mlp_tile_samples(int variant);  // samples per workgroup tile (32 or 64)
 size_t mlp_scratch_floats();

@@ -94,8 +94,8 @@ AMBIG = 1e-5   # fp32 reference-order forward (agrees with the oracle's pre-acti
 # The shipped DEFAULT training arithmetic (f16x2 kernel on the projected latent: another evaluation order, split-f16 matrix
 # products) reproduces the oracle's pre-activations to ~1e-5 instead of ~1e-6, so its comparisons select points / rays with a
 # wider margin.  Measured (tools/debug/margin_sweep.sh, profiles/r03_margin_sweep.log): the worst gradient error of the
-# default path against autograd through the oracle stops depending on the margin from 2e-5 on; 5e-5 is used.
-AMBIG_DEFAULT = float(os.environ.get("PNYOLO_TEST_AMBIG_DEFAULT", "5e-5"))
+# default path against autograd through the oracle is 2e-6 ... 1.7e-5 of a tensor's max at every margin from 1e-5 to 5e-5 (it fails only at margin 0: 5e-4, a flipped unit); 3e-5 is used.
+AMBIG_DEFAULT = float(os.environ.get("PNYOLO_TEST_AMBIG_DEFAULT", "3e-5"))
 
 
 # --------------------------------------------------------------------------- MLP (query) backward
