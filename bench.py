@@ -77,6 +77,19 @@ WORKLOADS = {
 }
 
 
+def kernel_source_fingerprint():
+    """sha256 over the sources of the dominant kernel (csrc/mlp_h2*.hip/.h, mlp_core.h): stored with the committed PMC traffic
+    figure (profiles/mlp_traffic.json, tools/summarize_prof.py) and recomputed here, so that a traffic figure profiled on
+    other kernel sources than the ones benched is marked stale in the line instead of passing silently."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "pixel-nerf-yolo_amd", "csrc")
+    for f in ("mlp_h2.hip", "mlp_h2_core.h", "mlp_core.h", "pny_common.h"):
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def flop_per_ray(workload, projected=False):
     """MLP GEMM FLOPs per ray (2/MAC, unpadded): reference operation order, or with lin_z moved to the
     per-scene projection."""
@@ -93,6 +106,64 @@ def describe(workload="c2"):
         "flop_per_ray_projected": flop_per_ray(workload, True),
         "config": {"workload": WORKLOADS[workload][7], "rays_per_frame": side * side},
     }
+
+
+def c3_leg(dev, args, steps=3):
+    """The C3 frame (128 x 128, 3 source views, L = 1792 latent at 16 x 16 supplied -- the YOLOv7 backbone is outside the
+    reference tree --, 64 + 32 (16) samples) timed like the main line: `steps` full frames between synchronisations."""
+    import torch
+    from pixel_nerf_yolo_amd import conf as pconf, synth
+    from pixel_nerf_yolo_amd.model import make_model
+    from pixel_nerf_yolo_amd.render import NeRFRenderer
+    from pixel_nerf_yolo_amd.util import gen_rays_range
+    side, d_latent, lat_side, kc, kf, kfd, _, desc = WORKLOADS["c3"]
+    mconf = pconf.default_mv()
+    mconf.d["model"]["encoder"]["backbone"] = "custom"
+    net = make_model(mconf["model"]).eval()
+    sd = {}
+    sd.update({"mlp_coarse." + k: v for k, v in synth.mlp_state(71, d_latent=d_latent).items()})
+    sd.update({"mlp_fine." + k: v for k, v in synth.mlp_state(72, d_latent=d_latent).items()})
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    net = net.to(dev)
+    net.set_latent_projection(args.projection)
+    net.set_matrix_precision(args.precision)
+    src, _ = synth.scene_cameras(NS)
+    focal, c = torch.tensor(FOCAL128 * side / 128.0), torch.tensor([[side * 0.5, side * 0.5]])
+    lat = torch.from_numpy(synth.latent(76, NS, d_latent, lat_side, lat_side)).to(dev)
+    images = torch.zeros(NS, 3, side, side, device=dev)
+    poses = torch.from_numpy(src)[None]
+    rays = gen_rays_range(torch.from_numpy(synth.pose_spherical(120.0, -20.0, 1.3))[None], side, side, focal, Z_NEAR, Z_FAR, 0,
+                          side * side, c=c[0], device=dev).reshape(1, -1, 8)
+    par = NeRFRenderer(n_coarse=kc, n_fine=kf, n_fine_depth=kfd, depth_std=0.01, white_bkgd=True).eval().bind_parallel(
+        net, None, simple_output=True).eval()
+
+    def step():
+        net.encode(images[None], poses, focal, c=c, latent=lat)
+        with torch.no_grad():
+            return par(rays)
+
+    step()
+    net.enable_kernel_timing(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ms = flops = 0.0
+    launches = 0
+    for _ in range(steps):
+        rgb, _ = step()
+        st = net.last_mlp_stats(full=True)
+        ms, flops, launches = ms + st["kernel_ms"], flops + st["flops"], launches + st["launches"]
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    net.enable_kernel_timing(False)
+    f16x2 = net.last_launch_f16x2()
+    peak = PEAK_F16X2_TFLOPS if f16x2 else PEAK_F32_MFMA_TFLOPS
+    ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else None
+    return {"workload": desc, "rays_per_s": side * side * steps / el, "steps": steps, "ms_per_step": el / steps * 1e3,
+            "ms_per_launch": ms / launches if launches else None, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+            "frac": ach / peak if ach else None, "flop_per_ray_reference_order": flop_per_ray("c3", False),
+            "finite": bool(torch.isfinite(rgb).all()),
+            "note": "north_star target config timed beside the C2 bench value (BASELINE.json's metric is quoted on C2, whose "
+                    "encoder is pinned); `bench.py --workload c3` gives the full line with cpu_baseline and parity"}
 
 
 def self_launch(args):
@@ -286,6 +357,7 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2",
                     help="c2 = BASELINE.json configs[1] (default, the bench line); c3/c4/c5 = configs[2..4]")
     ap.add_argument("--no-reference-order", action="store_true", help="skip the --projection off leg of the N=1 line")
+    ap.add_argument("--no-c3-leg", action="store_true", help="skip the C3 (north_star target config) leg of the default N=1 line")
     ap.add_argument("--mode", choices=["render", "train"], default="render",
                     help="render (default, the bench line) or train: one optimisation step of the reference's trainer "
                          "(train/trainlib/PixelNerfTrainer.py:58-156) on the C2 model")
@@ -478,12 +550,13 @@ def main():
 
     # HBM-side traffic of the dominant kernel cannot be counted from inside this process: it is the
     # committed rocprofv3 PMC measurement of the same command (tools/profile_gpu.sh -> profiles/mlp_traffic.json)
-    traffic = traffic_note = None
+    traffic = traffic_note = traffic_stale = None
     try:
         with open(os.path.join(ROOT, "profiles", "mlp_traffic.json")) as fh:
             tj = json.load(fh)
         if bool(tj.get("projected_latent")) == bool(projected) and bool(tj.get("f16x2")) == bool(acc["f16x2"]) and wl == "c2":
             traffic, traffic_note = tj["bytes_per_launch"], "%s: %s" % (tj["tag"], tj["method"])
+            traffic_stale = tj.get("kernel_sources_sha256") != kernel_source_fingerprint()
     except (OSError, ValueError, KeyError):
         pass
 
@@ -512,7 +585,10 @@ def main():
         }
 
     rl = roof(acc, value, world)
-    rl.update({"traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_note})
+    rl.update({"traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_note,
+               "traffic_stale": traffic_stale,
+               "traffic_stale_is": "true when the kernel sources benched differ from the ones the PMC figure was profiled on "
+                                   "(sha256 over csrc/mlp_h2.hip, mlp_h2_core.h, mlp_core.h, pny_common.h)"})
     out = {
         "metric": METRIC, "value": value, "unit": "rays/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -557,6 +633,11 @@ def main():
             "flop_per_ray": flop_per_ray(wl, False), "projected_latent": a2["projected"],
             "note": "--projection off: lin_z per (sample, view) as the reference orders it; not the bench value"}
         net.set_latent_projection(args.projection)
+
+    if world == 1 and wl == "c2" and not args.no_c3_leg:
+        # north_star's target config (BASELINE.json configs[2]: 3-view YOLO-sized conditioning, L = 1792) timed in the same
+        # run: 3 steps of the C3 frame (encode with the supplied latent + projection + render) on the default kernel
+        out["c3"] = c3_leg(dev, args)
 
     if rank == 0 and args.cpu_rays > 0 and world == 1:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))

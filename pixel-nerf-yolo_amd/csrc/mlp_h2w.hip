@@ -24,6 +24,29 @@ namespace pny {
 
 typedef float f32x4a __attribute__((ext_vector_type(4)));
 
+// Diagnostic build only (-DPNY_H2_STAMP): s_memtime brackets around the phases of a tile (as in mlp_h2.hip)
+#ifdef PNY_H2_STAMP
+enum { HS_TOTAL = 0, HS_GEMM, HS_GATHER_WAIT, HS_GATHER, HS_EPI_WAIT, HS_EPI, HS_PROLOGUE, HS_LINOUT, HS_SLAB, HS_REAL, HS_N };
+__device__ unsigned long long* g_h2w_stamp_buf;
+__device__ __forceinline__ unsigned long long hwnow() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define HS_T0() hs_t_ = hwnow()
+#define HS_LAP(cat)                            \
+    {                                          \
+        const unsigned long long n_ = hwnow(); \
+        hs_acc[cat] += n_ - hs_t_;             \
+        hs_t_ = n_;                            \
+    }
+#else
+#define HS_T0()
+#define HS_LAP(cat)
+#endif
+
 namespace hw {
 constexpr int NW = 4, THREADS = 64 * NW, TM = 64;
 constexpr int NT = 8, MT = 4;                 // 16 x 16 accumulator tiles per wave: 128 features x 64 samples
@@ -49,14 +72,26 @@ __device__ __forceinline__ h8 hwload(const WStream& ws, unsigned seg_off, int nt
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.lane_off, seg_off + (unsigned)(((j * 32 + nt) * 2 + p) * 64) * 16u, 0);
     return __builtin_bit_cast(h8, v);
 }
+// Weight fragments in flight: RD steps (of 32 k) ahead of the MFMAs.  One wave per SIMD has no partner wave to cover a
+// fetch that misses L2 (7 % of them do, served by the Infinity Cache at 2-3x the latency): with RD = 1 a fragment is
+// refetched 7/8 of a step (1.3 k cycles) before its next use and the GEMM phases run the matrix pipe at 78 %; RD = 2 gives
+// 15/8 of a step for 64 more registers.
+#ifndef PNY_HW_RD
+#define PNY_HW_RD 2
+#endif
+#ifndef PNY_HW_GD
+#define PNY_HW_GD 3   // gather pieces (32 registers each) in flight
+#endif
 struct HwRing {
-    h8 f[hw::NT][2];   // the fragments of the step about to be consumed
+    h8 f[PNY_HW_RD][hw::NT][2];   // slot d holds step j + d at the head of step j (rotating statically: steps are unrolled by 2)
 };
 __device__ __forceinline__ void hwring_fill(HwRing& r, const WStream& ws, const HwSeg& s) {
 #pragma unroll
-    for (int nt = 0; nt < hw::NT; ++nt)
+    for (int d = 0; d < PNY_HW_RD; ++d)
 #pragma unroll
-        for (int p = 0; p < 2; ++p) r.f[nt][p] = hwload(ws, s.off, nt, p, 0);
+        for (int nt = 0; nt < hw::NT; ++nt)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) r.f[d][nt][p] = hwload(ws, s.off, nt, p, d < s.jn ? d : s.jn - 1);
 }
 
 template <class Acc>
@@ -68,7 +103,8 @@ __device__ __forceinline__ void hwzero(Acc (&t)[hw::NT][hw::MT]) {
 }
 
 // One 32-k step: B = the step's activation fragments (4 m-tiles x 2 planes), Bn receives the next step's (read from `bnext`).
-// n-tile by n-tile: 12 MFMAs on the n-tile's two weight fragments, which are then refetched for the next step.
+// n-tile by n-tile: 12 MFMAs on the n-tile's two weight fragments (ring slot D), which are then refetched for step + RD.
+template <int D>
 __device__ __forceinline__ void hwstep(f32x4a (&acc)[hw::NT][hw::MT], HwRing& r, const h8 (&B)[hw::MT][2], h8 (&Bn)[hw::MT][2],
                                        const char* bnext, const WStream& ws, unsigned src, int jx) {
     using namespace hw;
@@ -76,15 +112,15 @@ __device__ __forceinline__ void hwstep(f32x4a (&acc)[hw::NT][hw::MT], HwRing& r,
     for (int nt = 0; nt < NT; ++nt) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(r.f[nt][0], B[mt][0], acc[nt][mt], 0, 0, 0);
+        for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(r.f[D][nt][0], B[mt][0], acc[nt][mt], 0, 0, 0);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(r.f[nt][0], B[mt][1], acc[nt][mt], 0, 0, 0);
+        for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(r.f[D][nt][0], B[mt][1], acc[nt][mt], 0, 0, 0);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(r.f[nt][1], B[mt][0], acc[nt][mt], 0, 0, 0);
+        for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(r.f[D][nt][1], B[mt][0], acc[nt][mt], 0, 0, 0);
         // one of the next step's 8 activation fragments per n-tile group
         Bn[nt >> 1][nt & 1] = *reinterpret_cast<const h8*>(bnext + (nt & 1) * ROW_BYTES + (nt >> 1) * 256);
-        r.f[nt][0] = hwload(ws, src, nt, 0, jx);
-        r.f[nt][1] = hwload(ws, src, nt, 1, jx);
+        r.f[D][nt][0] = hwload(ws, src, nt, 0, jx);
+        r.f[D][nt][1] = hwload(ws, src, nt, 1, jx);
 #ifndef PNY_H2_NOSCHED
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -95,10 +131,11 @@ __device__ __forceinline__ void hwstep(f32x4a (&acc)[hw::NT][hw::MT], HwRing& r,
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// acc += W_slice . act over segment `cur`; leaves the ring holding step 0 of `next`
+// acc += W_slice . act over segment `cur` (an even number of steps); leaves the ring holding the first RD steps of `next`
 __device__ __forceinline__ void hwgemm(f32x4a (&acc)[hw::NT][hw::MT], HwRing& r, const WStream& ws, const HwSeg& cur, const HwSeg& next,
                                        const char* planes, int lane) {
     using namespace hw;
+    constexpr int RD = PNY_HW_RD;
     const char* bp = planes + (lane >> 4) * (2 * ROW_BYTES) + (lane & 15) * 16;   // row 4 j + (lane >> 4), plane 0, sample lane & 15
     const int jn = cur.jn;
     h8 B0[MT][2], B1[MT][2];
@@ -107,9 +144,12 @@ __device__ __forceinline__ void hwgemm(f32x4a (&acc)[hw::NT][hw::MT], HwRing& r,
 #pragma unroll
         for (int p = 0; p < 2; ++p) B0[mt][p] = *reinterpret_cast<const h8*>(bp + p * ROW_BYTES + mt * 256);
     for (int j = 0; j < jn; j += 2) {
-        hwstep(acc, r, B0, B1, bp + (j + 1) * (8 * ROW_BYTES), ws, cur.off, j + 1);
+        // step j consumes slot 0 (RD = 1) / slot 0 (RD = 2) and refetches it with step j + RD; step j + 1 the other way round
+        const int ja = j + RD, jb = j + 1 + RD;
+        const bool ina = ja < jn, inb = jb < jn;
+        hwstep<0>(acc, r, B0, B1, bp + (j + 1) * (8 * ROW_BYTES), ws, ina ? cur.off : next.off, ina ? ja : ja - jn);
         const bool last = j + 2 >= jn;
-        hwstep(acc, r, B1, B0, bp + (last ? j + 1 : j + 2) * (8 * ROW_BYTES), ws, last ? next.off : cur.off, last ? 0 : j + 2);
+        hwstep<RD - 1>(acc, r, B1, B0, bp + (last ? j + 1 : j + 2) * (8 * ROW_BYTES), ws, inb ? cur.off : next.off, inb ? jb : jb - jn);
     }
 }
 
@@ -317,6 +357,12 @@ __global__ __launch_bounds__(hw::THREADS) __attribute__((amdgpu_waves_per_eu(1, 
     auto fc0_bias = [&](int b) -> const float* { return bias_tab + (1 + 2 * b) * HID; };
     HwRing ring;
     hwring_fill(ring, ws, s_in);
+#ifdef PNY_H2_STAMP
+    unsigned long long hs_acc[HS_N], hs_t_ = 0;
+    for (int i = 0; i < HS_N; ++i) hs_acc[i] = 0;
+    const unsigned long long hs_start = hwnow();
+    const unsigned long long hs_real0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int i = tid; i < (1 + 2 * nb) * HID; i += THREADS) {
         const int vec = i / HID, f = i % HID;
         const float* src = vec == 0 ? a.w.b_in : ((vec & 1) ? a.w.b_fc0[(vec - 1) >> 1] : a.w.b_fc1[(vec - 2) >> 1]);
@@ -335,49 +381,67 @@ __global__ __launch_bounds__(hw::THREADS) __attribute__((amdgpu_waves_per_eu(1, 
         f32x4a net[NT][MT];
         // one residual block from "planes hold relu(h_in)" on: net = fc_0(.), h += fc_1(relu(net + b_fc0))
         auto block_tail = [&](int blk, const HwSeg& after, bool slab_in) {
+            HS_T0();
             hwzero(net);
             __syncthreads();
+            HS_LAP(HS_EPI_WAIT);
             hwgemm(net, ring, ws, fc0seg(blk), fc1seg(blk), planes, lane);
+            HS_LAP(HS_GEMM);
             __syncthreads();
+            HS_LAP(HS_EPI_WAIT);
             hwepilogue<false>(net, fc0_bias(blk), planes, wave, lane, a.range_flag);
             if (slab_in) {
                 hwslab_load(net, slab);   // the other views' running sum, in the registers of the now dead `net`
+                HS_LAP(HS_EPI);
                 __syncthreads();
+                HS_LAP(HS_EPI_WAIT);
                 hwgemm(h, ring, ws, fc1seg(blk), after, planes, lane);
+                HS_LAP(HS_GEMM);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) h[nt][mt] = net[nt][mt] + h[nt][mt];
             } else {
+                HS_LAP(HS_EPI);
                 __syncthreads();
+                HS_LAP(HS_EPI_WAIT);
                 hwgemm(h, ring, ws, fc1seg(blk), after, planes, lane);
+                HS_LAP(HS_GEMM);
             }
         };
         for (int v = 0; v < a.NS; ++v) {
             const HwSeg after_view = v + 1 < a.NS ? s_in : (nvb < nb ? fc0seg(nvb) : s_in);
+            HS_T0();
             __syncthreads();
             hwprologue(a, v, tile, planes, tap_tab, tid);
             hwzero(h);
             __syncthreads();
+            HS_LAP(HS_PROLOGUE);
             hwgemm(h, ring, ws, s_in, fc0seg(0), planes, lane);
+            HS_LAP(HS_GEMM);
             for (int blk = 0; blk < nvb; ++blk) {
                 // h += interp(lin_z[blk](latent map)): the block's 512 projected channels in 16 pieces of 32 (one 128-byte line
                 // per tap and sample), four in flight
                 const int cb = blk * HID;
                 HwTaps g;
-                HwPiece pc[4];
+                HwPiece pc[PNY_HW_GD];
+                HS_T0();
                 __syncthreads();  // every wave is done reading the planes (previous GEMM)
+                HS_LAP(HS_GATHER_WAIT);
                 hwgather_setup(g, a.zp + (size_t)v * a.Hl * a.Wl * a.zp_stride, tap_tab, wave, lane);
 #pragma unroll
-                for (int i = 0; i < 3; ++i) hwgather_issue(pc[i], g, cb + 32 * i);
+                for (int i = 0; i < PNY_HW_GD - 1; ++i) hwgather_issue(pc[i], g, cb + 32 * i);
 #pragma unroll
                 for (int ln = 0; ln < 16; ++ln) {
-                    if (ln + 3 < 16) hwgather_issue(pc[(ln + 3) & 3], g, cb + 32 * (ln + 3));
+                    if (ln + PNY_HW_GD - 1 < 16) hwgather_issue(pc[(ln + PNY_HW_GD - 1) % PNY_HW_GD], g, cb + 32 * (ln + PNY_HW_GD - 1));
                     __builtin_amdgcn_sched_barrier(0);
-                    hwgather_commit(pc[ln & 3], g, planes, ln, wave, lane);
+                    hwgather_commit(pc[ln % PNY_HW_GD], g, planes, ln, wave, lane);
                 }
+                HS_LAP(HS_GATHER);
                 __syncthreads();  // projection visible
+                HS_LAP(HS_GATHER_WAIT);
                 hwepilogue<true>(h, entry_bias(blk), planes, wave, lane, a.range_flag);
+                HS_LAP(HS_EPI);
                 const bool last = blk + 1 == nvb;
                 block_tail(blk, last ? after_view : fc0seg(blk + 1), last && v > 0);
             }
@@ -394,11 +458,15 @@ __global__ __launch_bounds__(hw::THREADS) __attribute__((amdgpu_waves_per_eu(1, 
             }
         }
         for (int blk = nvb; blk < nb; ++blk) {
+            HS_T0();
             __syncthreads();
+            HS_LAP(HS_EPI_WAIT);
             hwepilogue<false>(h, entry_bias(blk), planes, wave, lane, a.range_flag);
+            HS_LAP(HS_EPI);
             block_tail(blk, blk + 1 < nb ? fc0seg(blk + 1) : s_in, false);
         }
         // out = lin_out(relu(h + b_fc1[last])) (reference resnetfc.py:185) + output head (models.py:312-317)
+        HS_T0();
         __syncthreads();
         hwepilogue<false>(h, entry_bias(nb), planes, wave, lane, a.range_flag);
         __syncthreads();
@@ -430,7 +498,14 @@ __global__ __launch_bounds__(hw::THREADS) __attribute__((amdgpu_waves_per_eu(1, 
             const long long s = tile * TM + m;
             if (s < a.n_points) a.out[s * a.d_out + o] = sum;
         }
+        HS_LAP(HS_LINOUT);
     }
+#ifdef PNY_H2_STAMP
+    hs_acc[HS_TOTAL] = hwnow() - hs_start;
+    hs_acc[HS_REAL] = __builtin_amdgcn_s_memrealtime() - hs_real0;
+    if (lane == 0)
+        for (int i = 0; i < HS_N; ++i) g_h2w_stamp_buf[((size_t)blockIdx.x * NW + wave) * HS_N + i] = hs_acc[i];
+#endif
 }
 
 bool mlp_h2w_supports(int n_blocks, int combine_layer) { return n_blocks <= hw::MAX_NB && combine_layer >= 1; }
@@ -445,7 +520,29 @@ void launch_mlp_h2w(const MlpArgs& a, int grid, hipStream_t st) {
                                   hw::lds_bytes(hw::MAX_NB));
         attr_set[dev_] = true;
     }
+#ifdef PNY_H2_STAMP
+    static unsigned long long* dbuf = nullptr;
+    const size_t nst = (size_t)grid * hw::NW * HS_N;
+    if (!dbuf) {
+        (void)hipMalloc((void**)&dbuf, (size_t)1024 * 8 * HS_N * sizeof(unsigned long long));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_h2w_stamp_buf), &dbuf, sizeof(dbuf));
+    }
+    (void)hipMemsetAsync(dbuf, 0, nst * sizeof(unsigned long long), st);
+#endif
     hipLaunchKernelGGL(pny_mlp_h2w_kernel, dim3(grid), dim3(hw::THREADS), hw::lds_bytes(a.n_blocks), st, a);
+#ifdef PNY_H2_STAMP
+    {
+        std::vector<unsigned long long> hst(nst);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(hst.data(), dbuf, nst * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        double sum[HS_N] = {0};
+        for (size_t i = 0; i < nst; ++i) sum[i % HS_N] += (double)hst[i];
+        static const char* names[HS_N] = {"total", "gemm", "gather-barrier-wait", "gather", "epilogue-barrier-wait", "epilogue", "prologue", "lin_out", "slab", "realtime"};
+        fprintf(stderr, "[h2w stamp] tiles=%d grid=%d:", a.n_tiles, grid);
+        for (int i = 0; i < HS_N; ++i) fprintf(stderr, " %s=%.1f%%", names[i], 100.0 * sum[i] / sum[0]);
+        fprintf(stderr, " (mean wave cycles %.4g; in-kernel clock %.3f GHz)\n", sum[0] / ((double)grid * hw::NW), sum[0] / sum[HS_REAL] * 0.1);
+    }
+#endif
 }
 
 }  // namespace pny

@@ -81,7 +81,9 @@ def main(tag):
                 names.add(r["Kernel_Name"].split("(")[0])
         per[cname] = tot / cnt if cnt else None
     if per["FETCH_SIZE"] is not None and per["WRITE_SIZE"] is not None:
-        traffic = {"tag": tag, "kernels": sorted(names), "projected_latent": any(", true>" in n or "pny_mlp_h2_kernel" in n for n in names),
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from bench import kernel_source_fingerprint   # the sources the counted kernel is built from, as profiled
+        traffic = {"tag": tag, "kernel_sources_sha256": kernel_source_fingerprint(), "kernels": sorted(names), "projected_latent": any(", true>" in n or "pny_mlp_h2_kernel" in n for n in names),
                    "f16x2": any("pny_mlp_h2_kernel" in n for n in names),
                    "fetch_kb_per_launch": per["FETCH_SIZE"], "write_kb_per_launch": per["WRITE_SIZE"],
                    "bytes_per_launch": (2.0 * per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024.0,
