@@ -221,6 +221,9 @@ class PixelNeRFNet(nn.Module):
 
     def __init__(self, conf, stop_encoder_grad=False):
         super().__init__()
+        self._conf = conf                  # kept for replicas on other devices (render._MultiDeviceRenderWrapper)
+        self._encode_epoch = 0             # bumped by every encode(): replicas re-fetch the scene state when it moved
+        self._last_encode = None
         self.encoder = make_encoder(conf["encoder"])
         self.use_encoder = conf.get_bool("use_encoder", True)
         self.use_xyz = conf.get_bool("use_xyz", False)
@@ -630,6 +633,9 @@ class PixelNeRFNet(nn.Module):
                 c = c.unsqueeze(-1).repeat(1, 2)
         c = c.contiguous()
         poses_h = poses.detach().to("cpu", torch.float32).contiguous()
+        self._encode_epoch += 1
+        self._last_encode = dict(poses=poses_h.reshape(SB, NS, 4, 4) if images is not None else poses_h, focal=focal, c=c, H=H, W=W,
+                                 NS=NS, SB=SB, five_d=self.num_views_per_obj == NS)
         st = stream_of(dev)
         if latent is None and self.encoder.use_custom_resnet:
             raise RuntimeError("backbone=custom (YOLOv7) has no kernels in this build (its source and weights are "

@@ -41,6 +41,176 @@ class _RenderWrapper(torch.nn.Module):
         return outputs  # plain nested dict, as DotMap.toDict() in the reference
 
 
+class _MultiDeviceRenderWrapper(torch.nn.Module):
+    """``bind_parallel(net, gpus)`` with more than one device in ONE process: the drop-in for the reference's
+    ``torch.nn.DataParallel(_RenderWrapper(...), gpus, dim=1)`` (src/render/nerf.py:360-377; called by train/train.py:78 and
+    eval/eval.py:150 with ``--gpu_id "0 1 ..."``) without its per-call replication.  The reference re-broadcasts every
+    parameter and the latent to every device on EVERY call; here each listed device holds a PERSISTENT
+    replica of the native model and of the encoded scenes:
+      * weights go up once and are re-sent only when the master's parameters changed (version counters),
+      * latent and cameras are re-sent only after the master's ``encode()`` (the encoder runs once, on the master),
+      * a call splits the rays on dim 1 into one contiguous range per device, enqueues every range on its device's stream
+        without waiting, and gathers the tiles on ``gpus[0]`` with peer copies.
+    Results: a ray renders to the same bits whatever range it is in (slice invariance), so with explicit draws
+    the assembled output equals the single-device call bit for bit; with Philox draws each range has its own seed.
+    Training calls (grad mode, trainable parameters) run on ``gpus[0]`` alone: data-parallel training in this framework is
+    one process per GPU (dist.allreduce_gradients); the call sites still run unchanged.  dist.py stays the recommended
+    multi-GPU path (no Python serialisation of the per-device launches)."""
+
+    def __init__(self, net, renderer, gpus, simple_output):
+        super().__init__()
+        self.net, self.renderer, self.simple_output = net, renderer, simple_output
+        self.gpus = [int(g) for g in gpus]
+        self._replicas = [None] * len(self.gpus)   # [0] is `net` itself when it lives on gpus[0]
+        self._seen = [None] * len(self.gpus)       # (weights key, encode epoch) each replica was last synchronised to
+        self._warned = False
+
+    def _replica(self, i):
+        from .model import PixelNeRFNet
+        net = self.net
+        dev = torch.device("cuda", self.gpus[i])
+        if i == 0 and net._device() == dev:
+            return net
+        r = self._replicas[i]
+        if r is None:
+            r = PixelNeRFNet(net._conf, stop_encoder_grad=True)
+            if net.mlp_fine is None:
+                r.mlp_fine = None
+            r.load_state_dict(net.state_dict(), strict=False)
+            r = r.to(dev).eval()
+            r._projection, r._precision = net._projection, net._precision
+            self._replicas[i] = r
+        key = (net._weights_key(), net._encode_epoch)
+        if self._seen[i] != key:
+            if self._seen[i] is not None and self._seen[i][0] != key[0]:
+                with torch.no_grad():      # in place: the replica's refresh path (one repack launch), not a re-upload
+                    for (k, dst), (_, src) in zip(r.state_dict().items(), net.state_dict().items()):
+                        dst.copy_(src)
+                if (net.mlp_fine is None) != (r.mlp_fine is None):
+                    r.mlp_fine = None
+            le = net._last_encode
+            if le is None:
+                raise RuntimeError("bind_parallel(net, gpus): call net.encode(...) before rendering")
+            with torch.cuda.device(dev):
+                lat = torch.cat([net.latent(sb) for sb in range(le["SB"])]).to(dev)
+                images = torch.zeros(le["SB"], le["NS"], 3, le["H"], le["W"])
+                r.encode(images, le["poses"], le["focal"], c=le["c"], latent=lat)
+            self._seen[i] = key
+        return r
+
+    def forward(self, rays, want_weights=False):
+        if rays.shape[0] == 0:
+            return (torch.zeros(0, 3, device=rays.device), torch.zeros(0, device=rays.device))
+        net, ren = self.net, self.renderer
+        want_weights = want_weights and not self.simple_output
+        training = torch.is_grad_enabled() and net.training and (net.trainable_mlp_parameters() or net.differentiable_latent() is not None)
+        B = rays.shape[1]
+        n_dev = len(self.gpus)
+        if training or B < 64 * n_dev:
+            if training and not self._warned:
+                import warnings
+                warnings.warn("bind_parallel(net, gpus=%s): training calls run on cuda:%d alone (data-parallel training is one "
+                              "process per GPU here: pixel_nerf_yolo_amd.dist)" % (self.gpus, self.gpus[0]))
+                self._warned = True
+            outputs = ren(net, rays, want_weights=want_weights)
+        else:
+            outputs = self._render_split(rays, want_weights)
+        if self.simple_output:
+            part = outputs["fine"] if "fine" in outputs else outputs["coarse"]
+            return part["rgb"], part["depth"]
+        return outputs
+
+    def _render_split(self, rays, want_weights):
+        net, ren = self.net, self.renderer
+        SB, B = rays.shape[0], rays.shape[1]
+        n_dev = len(self.gpus)
+        per = -(-B // n_dev)
+        per = -(-per // 64) * 64                   # whole 64-ray groups per device
+        bounds = [(min(B, i * per), min(B, (i + 1) * per)) for i in range(n_dev)]
+        draws, calls = ren.draws, ren._calls
+        ren.draws = None
+        reps = [self._replica(i) if hi > lo else None for i, (lo, hi) in enumerate(bounds)]
+        master_policy = net.f16_range_policy
+
+        def part(i, only_f32=False):
+            lo, hi = bounds[i]
+            r = reps[i]
+            dev = torch.device("cuda", self.gpus[i])
+            if only_f32:
+                r.set_matrix_precision("f32")
+            with torch.cuda.device(dev):
+                ren._calls = calls + i
+                if draws is not None:
+                    ren.draws = {k: torch.as_tensor(v).reshape(SB, B, -1)[:, lo:hi].reshape(SB * (hi - lo), -1) for k, v in draws.items()}
+                return ren._render(r, rays[:, lo:hi].to(dev), want_weights, save=False)[0]
+
+        try:
+            outs = [part(i) if reps[i] is not None else None for i in range(n_dev)]
+            # f16-range guard (model.guard_f16_range), after every device has its work: wait per device, repeat a range on fp32
+            for i, r in enumerate(reps):
+                if r is None or master_policy == "lazy" or not any(r.last_launch_f16x2(s) for s in range(len(r._h_scenes))):
+                    continue
+                torch.cuda.current_stream(torch.device("cuda", self.gpus[i])).synchronize()
+                bits = r.range_status(clear=False)
+                if bits:
+                    r.range_status(clear=True)
+                    if master_policy == "raise":
+                        raise _lib.PnyRangeError(r._range_message(bits))
+                    import warnings
+                    warnings.warn("libpnyolo: " + r._range_message(bits) + " -- repeating the rays of cuda:%d on the fp32 kernels" % self.gpus[i])
+                    outs[i] = part(i, only_f32=True)
+        finally:
+            ren._calls = calls + n_dev
+        dev0 = torch.device("cuda", self.gpus[0])
+        res = {}
+        for p in outs[[o is not None for o in outs].index(True)]:
+            res[p] = {k: torch.cat([o[p][k].to(dev0) for o in outs if o is not None], dim=1) for k in outs[0][p]}
+        return res
+
+
+class _MultiDeviceYoloWrapper(_MultiDeviceRenderWrapper):
+    """``YoloRenderer.bind_parallel(net, gpus)`` with several devices (reference src/render/yolo.py:116-121 wraps the renderer in
+    DataParallel(dim=1)): the same persistent replicas, the rays (flattened to (N, 8) as YoloRenderer.forward does) split into
+    one contiguous range per device, the (n, anchors, 7) results concatenated on gpus[0]."""
+
+    def __init__(self, net, renderer, gpus):
+        super().__init__(net, renderer, gpus, simple_output=False)
+
+    def forward(self, rays):
+        net, ren = self.net, self.renderer
+        training = torch.is_grad_enabled() and net.training and (net.trainable_mlp_parameters() or net.differentiable_latent() is not None)
+        flat = rays.reshape(-1, 8)
+        N, n_dev = flat.shape[0], len(self.gpus)
+        if training or N < 64 * n_dev:
+            ren.net = net
+            return ren(rays)
+        per = -(-(-(-N // n_dev)) // 64) * 64
+        bounds = [(min(N, i * per), min(N, (i + 1) * per)) for i in range(n_dev)]
+        draws, calls = ren.draws, ren._calls
+        outs = []
+        try:
+            for i, (lo, hi) in enumerate(bounds):
+                if hi <= lo:
+                    continue
+                r = self._replica(i)
+                dev = torch.device("cuda", self.gpus[i])
+                with torch.cuda.device(dev):
+                    ren.net, ren._calls = r, calls + i
+                    ren.draws = None if draws is None else {"u_coarse": torch.as_tensor(draws["u_coarse"]).reshape(N, -1)[lo:hi]}
+                    outs.append((i, r, ren._render(flat[lo:hi].to(dev))[0]))
+            for i, r, _ in outs:   # f16-range guard, after every device has its work
+                if net.f16_range_policy == "lazy" or not r.last_launch_f16x2():
+                    continue
+                torch.cuda.current_stream(torch.device("cuda", self.gpus[i])).synchronize()
+                bits = r.range_status(clear=True)
+                if bits:
+                    raise _lib.PnyRangeError(r._range_message(bits))
+        finally:
+            ren.net, ren._calls, ren.draws = net, calls + n_dev, None
+        dev0 = torch.device("cuda", self.gpus[0])
+        return torch.cat([o.to(dev0) for _, _, o in outs], dim=0)
+
+
 class _RenderFunction(torch.autograd.Function):
     """NeRFRenderer.forward under autograd: forward = the ordinary pny_render (with its z / per-sample outputs kept),
     backward = pny_render_backward per scene, which accumulates into gradient buffers bound to the MLP parameters."""
@@ -299,14 +469,12 @@ class NeRFRenderer(torch.nn.Module):
                    sched=conf.get_list("sched", None))
 
     def bind_parallel(self, net, gpus=None, simple_output=False):
-        """reference nerf.py:360-377.  The reference wraps the module in a single-process
-        ``DataParallel(dim=1)`` that re-broadcasts all parameters and the latent on every call;
-        here multi-GPU is one process per GPU (dist.py: ray sharding + one RCCL all-gather), so a
-        `gpus` list longer than one is refused rather than silently run on one device."""
+        """reference nerf.py:360-377.  The reference wraps the module in a single-process ``DataParallel(dim=1)`` that
+        re-broadcasts all parameters and the latent on every call; a `gpus` list longer than one gives the same call
+        signature on persistent per-device replicas instead (_MultiDeviceRenderWrapper).  The recommended multi-GPU path
+        stays one process per GPU (dist.py: per-rank ray generation + one RCCL all-gather)."""
         if gpus is not None and len(gpus) > 1:
-            raise NotImplementedError(
-                "multi-GPU rendering is one process per GPU in this framework: launch with "
-                "torch.distributed.run and use pixel_nerf_yolo_amd.dist.render_sharded (see INTEGRATION.md)")
+            return _MultiDeviceRenderWrapper(net, self, gpus, simple_output=simple_output)
         return _RenderWrapper(net, self, simple_output=simple_output)
 
 
@@ -376,9 +544,11 @@ class YoloRenderer(torch.nn.Module):
         return out, dict(rays=rays, u=u, seed=seed, raw=raw, n_coarse=int(self.n_coarse))
 
     def bind_parallel(self, net, gpus=None):
+        """reference yolo.py:116-121 (DataParallel(self, gpus, dim=1) for several devices: here persistent per-device
+        replicas, _MultiDeviceYoloWrapper)."""
         self.net = net
         if gpus is not None and len(gpus) > 1:
-            raise NotImplementedError("multi-GPU: one process per GPU (pixel_nerf_yolo_amd.dist), not DataParallel")
+            return _MultiDeviceYoloWrapper(net, self, gpus)
         return self
 
 

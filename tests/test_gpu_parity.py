@@ -189,8 +189,56 @@ def test_simple_output_and_wrapper(golden):
     with torch.no_grad():
         d = par2(dt(g["rays"])[None])
     assert set(d.keys()) == {"coarse", "fine"} and set(d["fine"].keys()) == {"rgb", "depth"}
-    with pytest.raises(NotImplementedError):
-        ren.bind_parallel(net, [0, 1])
+
+
+def test_bind_parallel_several_devices_in_one_process(golden):
+    """bind_parallel(net, gpus) with len(gpus) > 1 (reference nerf.py:360-377 -> DataParallel(dim=1); train.py:78 and
+    eval.py:150 call it with --gpu_id "0 1"): persistent per-device replicas, rays split on dim 1, tiles gathered on gpus[0].
+    One GPU here, so gpus = [0, 0] (two replicas on the same device) and [0, 0, 0]: with explicit draws the assembled output
+    equals the single call bit for bit (a ray's result does not depend on the range it is rendered in); a second encode()
+    and an in-place weight update on the master reach the replicas; Philox draws and the simple_output tuple work."""
+    g = golden("nerf_c2")
+    net = nerf_net(g, 7)
+    ren = make_renderer(pconf.default_mv()).eval()
+    n = 100
+    rs = np.random.RandomState(3)
+    rays = dt(np.tile(g["rays"], (3, 1))[:256 + 37])[None]                 # 293 rays: ragged ranges
+    N = rays.shape[1]
+    draws = dict(u_coarse=rs.rand(N, 64).astype(np.float32), u_fine=rs.rand(N, 16).astype(np.float32),
+                 u_fine2=rs.rand(N, 16).astype(np.float32), g_depth=rs.randn(N, 16).astype(np.float32))
+
+    def run(par, **kw):
+        ren.draws = dict(draws)
+        with torch.no_grad():
+            return par(rays, **kw)
+
+    single = run(ren.bind_parallel(net, [0]), want_weights=True)
+    for gpus in ([0, 0], [0, 0, 0]):
+        par = ren.bind_parallel(net, gpus)
+        multi = run(par, want_weights=True)
+        for p_ in ("coarse", "fine"):
+            for k in ("rgb", "depth", "weights"):
+                assert multi[p_][k].device == torch.device(DEV) and torch.equal(multi[p_][k], single[p_][k]), (gpus, p_, k)
+    par = ren.bind_parallel(net, [0, 0])
+    # the master encodes another scene (other latent) and steps a weight in place: both reach the replica
+    H, W, ns = int(g["H"]), int(g["W"]), int(g["NS"])
+    lat2 = torch.from_numpy(synth.latent(991, ns, 512, H // 2, W // 2))
+    net.encode(torch.zeros(1, ns, 3, H, W), torch.from_numpy(g["src_poses"])[None], torch.tensor(float(g["focal"])),
+               c=torch.from_numpy(g["c"])[None], latent=lat2)
+    with torch.no_grad():
+        net.mlp_coarse.lin_out.bias.add_(0.25)
+    single2 = run(ren.bind_parallel(net, None))
+    multi2 = run(par)
+    assert not torch.equal(single2["fine"]["rgb"], single["fine"]["rgb"])
+    for p_ in ("coarse", "fine"):
+        assert torch.equal(multi2[p_]["rgb"], single2[p_]["rgb"]) and torch.equal(multi2[p_]["depth"], single2[p_]["depth"])
+    # simple_output + Philox draws (no explicit tensors): shapes, finiteness, and the empty-ray guard
+    par_s = ren.bind_parallel(net, [0, 0], simple_output=True).eval()
+    with torch.no_grad():
+        rgb, depth = par_s(rays)
+    assert rgb.shape == (1, N, 3) and depth.shape == (1, N) and bool(torch.isfinite(rgb).all())
+    e_rgb, e_d = par_s(torch.zeros(0, 5, 8, device=DEV))
+    assert e_rgb.shape == (0, 3) and e_d.shape == (0,)
 
 
 # --------------------------------------------------------------------------- stages via the ABI
@@ -268,6 +316,14 @@ def test_yolo_render_golden(golden, projection):
     assert out.shape == (n, 3, 7) and maxabs(out, g["yolo_out"]) < TOL * scale
     rays_all = gen_rays_yolo(dt(g["tgt_w2c"])[None], int(g["Wc"]), int(g["Hc"]), g["focal"] / 8, g["c"] / 8, 1.0, 13.0)
     assert maxabs(rays_all[0], g["rays_all"]) < 1e-5
+    # YoloRenderer.bind_parallel(net, gpus) with several devices (reference yolo.py:116-121): two replicas on this GPU, bit-equal
+    par2 = ren.bind_parallel(net, [0, 0])
+    ren._debug_raw = None
+    ren.draws = dict(u_coarse=g["u_coarse"])
+    with torch.no_grad():
+        out2 = par2(dt(g["rays"])[None])
+    ren.bind_parallel(net)
+    assert out2.shape == out.shape and torch.equal(out2, out)
     # backbone=custom without a supplied latent must fail loudly (no silent fallback)
     with pytest.raises(RuntimeError):
         net.encode(torch.zeros(1, 3, 3, 128, 128), torch.from_numpy(g["src_w2c"])[None], torch.from_numpy(g["focal"])[None])
