@@ -104,7 +104,11 @@ __device__ __forceinline__ void h2group_sync(unsigned* cnt, unsigned& epoch, int
 // hazard (tools/ubench/lds_write_data_hazard.hip), so what else contributed here is open; this form is the safe one.
 __device__ __forceinline__ void stash_store(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, float a, float b, float c, float d) {
     const f32x4 v = {a, b, c, d};
+#ifdef PNY_H2_ANOM_SOFF   // diagnosis only (profiles/r03_anomalies.md): the form that fails -- slot offset in the SGPR soffset
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, voff, __builtin_amdgcn_readfirstlane(soff), 0);
+#else
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, voff + soff, 0, 0);
+#endif
 }
 
 // STASH (training forward): relu(acc + ...) is also written in fp32 to `stash` in the [feature/4][sample] float4 tile layout of
@@ -479,7 +483,15 @@ __global__ __launch_bounds__(h2::THREADS, 2) void PNY_H2_KERNEL(const MlpArgs a)
                 // from here two chunks are in flight: the loads of chunk c + 1 are issued before chunk c is blended.
                 const int cb = blk * HID;
                 HS_LAP(HS_GATHER);
+#ifdef PNY_H2_ANOM_VMCNT0   // diagnosis of the packed-f32 anomaly: every load landed before chunk 0 is blended?
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#endif
                 H2SYNC();  // every wave is done reading the planes (previous GEMM)
+#ifdef PNY_H2_ANOM_SCHEDBAR   // diagnosis: nothing of the blend may be scheduled above the barrier
+                __builtin_amdgcn_sched_barrier(0);
+#endif
                 HS_LAP(HS_GATHER_WAIT);
                 gather_issue<C, 1>(g, cb + GCH, wave);
                 __builtin_amdgcn_sched_barrier(0);
