@@ -315,7 +315,9 @@ def train_main(args):
         "data": "synthetic",
         "config": {"workload": "train step of the C2 model: SB=4 objects x 3 views 128x128 (%s), 128 rays/object, 64 coarse + "
                                "32 fine (16 depth), MSE coarse+fine, Adam" % (
-                                   "ResNet34 trunk TRAINED: torch graph forward / backward + latent-gradient kernel"
+                                   ("ResNet34 trunk TRAINED, batch-statistics batch norm: %s + latent-gradient kernel"
+                                    % ("ATen graph forward / backward (PNYOLO_TRUNK=torch)" if os.environ.get("PNYOLO_TRUNK") == "torch"
+                                       else "this library's training kernels forward / backward (csrc/encoder_train.hip)"))
                                    if args.train_encoder else "frozen ResNet34 trunk encoded every step"),
                    "rays_per_step": world * SB * RB, "rays_per_step_this_rank": SB * RB,
                    "parallelism": "dp%d: one super-batch per rank, 1 gradient all-reduce (27 MB fp32) per step" % world},
@@ -330,6 +332,8 @@ def train_main(args):
                                  for n_, m_, f_ in zip(names, k_ms, k_fl)]},
         "cpu_baseline": None,
     }
+    if os.environ.get("PNYOLO_BENCH_STEP_TIMES"):
+        out["step_ms"] = step_ms
     if args.rehearse_one_gpu:
         out["rehearsal"] = "ranks share ONE GPU, gloo transport: mechanics check, not a measurement"
     if rank == 0:

@@ -284,6 +284,21 @@ int pny_scene_last_precision(pny_scene* s, int* f16x2);
 #define PNY_RANGE_WEIGHT 4u
 int pny_model_range_status(pny_model* m, unsigned* bits, int clear);
 
+/* The ResNet-34 trunk in TRAINING mode (reference src/model/encoder.py:139-173 under autograd with the encoder unfrozen, the
+ * default of train/train.py:66-73; batch norm on batch statistics as nn.BatchNorm2d in train()): forward and backward as this
+ * library's kernels (csrc/encoder_train.hip).  Parameters are read where PyTorch keeps them: bind every `encoder.model.*`
+ * tensor the trunk uses (conv `.weight`; bn `.weight`, `.bias`, `.running_mean`, `.running_var`) with pny_model_bind_param
+ * first, and the gradient buffers of the trainable ones with pny_model_bind_grad.
+ * pny_trunk_train_forward: images (n_images, 3, H, W) NCHW in [-1, 1] -> latent (n_images, 512, H/2, W/2) NCHW (the layout
+ * PixelNeRFNet.encode(latent=) takes); running_mean / running_var are stepped in place with `momentum` (0.1 in the reference's
+ * modules; 0 leaves them alone); bn_eval != 0 normalises with the running statistics instead (modules in eval() mode while
+ * their parameters still train) and leaves them alone.  The activations stay in the model handle for ONE backward.
+ * pny_trunk_train_backward: d loss / d latent (same shape) -> every bound gradient buffer is WRITTEN (conv weights in
+ * (cout, cin, k, k), bn weight / bias).  Deterministic (no atomics). */
+int pny_trunk_train_forward(pny_model* m, const float* images_dev, int n_images, int height, int width, float momentum, int bn_eval,
+                            float* latent_nchw_dev, pny_stream stream);
+int pny_trunk_train_backward(pny_model* m, const float* d_latent_nchw_dev, pny_stream stream);
+
 /* Introspection for bench.py: GEMM FLOPs (2/MAC, unpadded, MLP only) of the last pny_render /
  * pny_query on this scene -- `flops` as executed by the fused kernel, `flops_reference` as the
  * reference's operation order would execute them (equal when the projection is off) --, the HIP-event

@@ -354,35 +354,38 @@ def yolo_render(scene, rays, n_coarse, u_coarse, n_anchors=3, chunk=50000):
 
 
 # ----------------------------------------------------------------------------- encoder
-def _bn(sd, name, x):
+def _bn(sd, name, x, training=False):
+    """nn.BatchNorm2d as torchvision's ResNet holds it (eps 1e-5, momentum 0.1): eval() mode normalises with the running
+    statistics; train() mode with the batch's and steps running_mean / running_var IN PLACE (sd's tensors)."""
     return F.batch_norm(x, sd[name + ".running_mean"], sd[name + ".running_var"], sd[name + ".weight"],
-                        sd[name + ".bias"], training=False, eps=1e-5)
+                        sd[name + ".bias"], training=training, momentum=0.1, eps=1e-5)
 
 
-def _block(sd, p, x, stride):
+def _block(sd, p, x, stride, training=False):
     idt = x
     if (p + "downsample.0.weight") in sd:
-        idt = _bn(sd, p + "downsample.1", F.conv2d(x, sd[p + "downsample.0.weight"], stride=stride))
-    out = torch.relu(_bn(sd, p + "bn1", F.conv2d(x, sd[p + "conv1.weight"], stride=stride, padding=1)))
-    out = _bn(sd, p + "bn2", F.conv2d(out, sd[p + "conv2.weight"], padding=1))
+        idt = _bn(sd, p + "downsample.1", F.conv2d(x, sd[p + "downsample.0.weight"], stride=stride), training)
+    out = torch.relu(_bn(sd, p + "bn1", F.conv2d(x, sd[p + "conv1.weight"], stride=stride, padding=1), training))
+    out = _bn(sd, p + "bn2", F.conv2d(out, sd[p + "conv2.weight"], padding=1), training)
     return torch.relu(out + idt)
 
 
-def spatial_encoder(sd, images, prefix="encoder.model.", use_first_pool=True):
-    """src/model/encoder.py:139-173 with num_layers=4, use_first_pool, eval-mode batch norm:
+def spatial_encoder(sd, images, prefix="encoder.model.", use_first_pool=True, training=False):
+    """src/model/encoder.py:139-173 with num_layers=4, use_first_pool; batch norm in eval() mode, or -- training=True, the
+    trunk as train/train.py leaves it without --freeze_enc -- on batch statistics (running statistics of `sd` stepped in place):
     conv1/bn1/relu -> L0; maxpool, layer1 -> L1; layer2 -> L2; layer3 -> L3; every level
     bilinearly upsampled (align_corners=True) to L0's size; channel concat (64+64+128+256).
     ResNet-34 BasicBlock layout [3,4,6] restated from the public architecture (torchvision is
     absent: PARITY UNPINNED at that boundary).  Returns (latent NCHW, [levels])."""
     sd = {k[len(prefix):]: T(v) for k, v in sd.items() if k.startswith(prefix)}
     x = T(images)
-    x = torch.relu(_bn(sd, "bn1", F.conv2d(x, sd["conv1.weight"], stride=2, padding=3)))
+    x = torch.relu(_bn(sd, "bn1", F.conv2d(x, sd["conv1.weight"], stride=2, padding=3), training))
     levels = [x]
     if use_first_pool:  # encoder.py:145-146 (sn64.conf sets use_first_pool = False)
         x = F.max_pool2d(x, 3, 2, 1)
     for li, n in ((1, 3), (2, 4), (3, 6)):
         for b in range(n):
-            x = _block(sd, "layer%d.%d." % (li, b), x, 2 if (b == 0 and li > 1) else 1)
+            x = _block(sd, "layer%d.%d." % (li, b), x, 2 if (b == 0 and li > 1) else 1, training)
         levels.append(x)
     size = levels[0].shape[-2:]
     ups = [F.interpolate(l, size, mode="bilinear", align_corners=True) for l in levels]

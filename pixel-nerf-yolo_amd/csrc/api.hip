@@ -363,6 +363,7 @@ void pny_model_destroy(pny_model* m) {
     m->enc.release();
     for (float* p : m->zproj_allocs) (void)hipFree(p);
     if (m->range_flag) (void)hipHostFree(m->range_flag);
+    trunk_release(m->trunk);
     delete m;
 }
 

@@ -113,6 +113,11 @@ struct MlpWeightsT {
 
 }  // namespace pny
 
+namespace pny {
+struct TrunkTrain;                       // training-mode trunk: saved activations and scratch (encoder_train.hip)
+void trunk_release(TrunkTrain* t);
+}  // namespace pny
+
 using namespace pny;  // private header of host-side translation units only
 
 struct pny_model {
@@ -149,6 +154,7 @@ struct pny_model {
     EncoderWeights enc;                       // folded conv+bn (encoder.h)
     DevBuf enc_batch_work, enc_batch_lat;     // pny_scenes_encode: workspace and result of one trunk pass over several scenes
     bool has_encoder = false;
+    TrunkTrain* trunk = nullptr;              // created by the first pny_trunk_train_forward
     // lin_z[0..nvb) of the coarse / fine MLP stacked into one (nvb*512 x d_latent) pixel-wise map
     ConvLayer zproj[2];
     std::vector<float*> zproj_allocs;

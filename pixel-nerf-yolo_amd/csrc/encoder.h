@@ -38,6 +38,11 @@ bool build_pixel_linear(const float* const* mats, int nmat, int rows, int k, Con
 // f16x2: split-f16 matrix products (pixel_linear_h2_kernel) instead of the fp32 MFMA
 bool run_pixel_linear(const ConvLayer& L, const float* in, long long npix, float* out, hipStream_t st, bool f16x2 = false);
 
+// One convolution through conv_mfma_kernel (encoder.hip): out = relu?(conv(in) * L.scale + L.shift + resid), channel-last.
+// hout / wout explicit; dil_shift > 0 reads the input as if 2^dil_shift - 1 zeros stood between its samples.
+bool run_conv_ex(const ConvLayer& L, const float* in, int n, int hin, int win, int hout, int wout, int dil_shift, const float* resid,
+                 int relu, float* out, hipStream_t st);
+int conv_out(int in, int k, int s, int p);
 void encoder_latent_size(int height, int width, int* hl, int* wl);
 size_t encoder_workspace_bytes(int ns, int height, int width, bool use_first_pool);
 // images (ns,3,H,W) NCHW -> latent (ns, H0, W0, 512) channel-last

@@ -27,6 +27,8 @@ struct ConvArgs {
     const float* resid;
     float* out;
     int n, hin, win, cin_p, hout, wout, cout, k, stride, pad, J, relu;
+    int dil_shift;   // input dilation 1 << dil_shift: the transposed convolution of the backward pass reads the gradient of a
+                     // stride-2 convolution at every second position of the output grid (encoder_train.hip); 0 otherwise
     long long npix;
 };
 
@@ -89,8 +91,15 @@ __global__ __launch_bounds__(SPLIT == 1 ? 256 : 512) void conv_mfma_kernel(const
         for (int nt = 0; nt < NT; ++nt) f.a[nt] = w0[((size_t)nt * a.J + jj) * 64];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int iy = iy0[mt] + ky, ix = ix0[mt] + kx;
-            const bool ok = valid[mt] && tap < ntap && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
+            int iy = iy0[mt] + ky, ix = ix0[mt] + kx;
+            bool ok = valid[mt] && tap < ntap && iy >= 0 && ix >= 0;
+            if (a.dil_shift) {   // positions between the samples of a dilated input are zeros
+                const int msk = (1 << a.dil_shift) - 1;
+                ok = ok && !(iy & msk) && !(ix & msk);
+                iy >>= a.dil_shift;
+                ix >>= a.dil_shift;
+            }
+            ok = ok && iy < a.hin && ix < a.win;
             f.b[mt] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ok) f.b[mt] = *reinterpret_cast<const float4*>(a.in + (((size_t)img[mt] * a.hin + iy) * a.win + ix) * a.cin_p + ci);
         }
@@ -606,7 +615,7 @@ void EncoderWeights::release() {
     for (auto& l : layers) l.clear();
 }
 
-static int conv_out(int in, int k, int s, int p) { return (in + 2 * p - k) / s + 1; }
+int conv_out(int in, int k, int s, int p) { return (in + 2 * p - k) / s + 1; }
 
 void encoder_latent_size(int height, int width, int* hl, int* wl) {
     *hl = conv_out(height, 7, 2, 3);
@@ -643,6 +652,13 @@ size_t encoder_workspace_bytes(int ns, int height, int width, bool use_first_poo
 
 static bool run_conv(const ConvLayer& L, const float* in, int n, int hin, int win, const float* resid, int relu,
                      float* out, hipStream_t st) {
+    return run_conv_ex(L, in, n, hin, win, conv_out(hin, L.k, L.stride, L.pad), conv_out(win, L.k, L.stride, L.pad), 0, resid, relu,
+                       out, st);
+}
+
+// The general form: explicit output size and an input dilation (transposed convolutions of the trunk's backward).
+bool run_conv_ex(const ConvLayer& L, const float* in, int n, int hin, int win, int hout, int wout, int dil_shift, const float* resid,
+                 int relu, float* out, hipStream_t st) {
     ConvArgs a;
     a.in = in;
     a.w = L.w;
@@ -654,8 +670,9 @@ static bool run_conv(const ConvLayer& L, const float* in, int n, int hin, int wi
     a.hin = hin;
     a.win = win;
     a.cin_p = L.cin_p;
-    a.hout = conv_out(hin, L.k, L.stride, L.pad);
-    a.wout = conv_out(win, L.k, L.stride, L.pad);
+    a.hout = hout;
+    a.wout = wout;
+    a.dil_shift = dil_shift;
     a.cout = L.cout;
     a.k = L.k;
     a.stride = L.stride;

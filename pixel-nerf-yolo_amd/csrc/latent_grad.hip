@@ -129,10 +129,170 @@ __global__ __launch_bounds__(64 * LG_NW) void latent_grad_kernel(const MlpArgs a
     }
 }
 
+// The same kernel on split-f16 matrix products (x1 w1 + x2 w1 + x1 w2 on v_mfma_f32_32x32x16_f16, fp32 accumulation: the
+// arithmetic of mlp_h2.hip / pixel_linear_h2_kernel), for scenes whose backward runs the f16x2 kernels: the GEMM is 8 launches
+// and ~0.4 TFLOP of a training step with the encoder unfrozen.  Gradients have no fixed magnitude, so the B operand is
+// multiplied by the power of two that puts the launch's max |dY| (tracked by the chain kernel, BwdArgs::dy_absmax) at
+// 2^13 .. 2^14 before it is split, and the accumulators by its inverse on the way out (exact), as pny_dw_gemm_h2_kernel does.
+typedef _Float16 lgh8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void lg_split2(float a, float b, unsigned& p0, unsigned& p1) {
+    float ra, rb;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p0) : "v"(a), "v"(b));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(p0), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(p0), "v"(b));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p1) : "v"(ra), "v"(rb));
+}
+
+__global__ __launch_bounds__(64 * LG_NW) void latent_grad_h2_kernel(const MlpArgs a, const float* __restrict__ dy_stash, const StashLayout lay,
+                                                                    const float* __restrict__ w_cat, float* __restrict__ grad, int nvb,
+                                                                    const unsigned* __restrict__ dy_absmax) {
+    __shared__ uint2 bp[2][2][LG_KC / 4][64 + 1];   // [buffer][plane][k / 4][sample]
+    __shared__ __attribute__((aligned(16))) float tr[LG_NW][32][68];
+    __shared__ int tap_off[64][4];
+    __shared__ float tap_w[64][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = lane & 31, hh = lane >> 5;
+    const int nblocks = a.L / 256;
+    const int nb = blockIdx.x % nblocks;
+    const long long tv = blockIdx.x / nblocks;
+    const int v = (int)(tv % a.NS);
+    const long long tile = tv / a.NS;
+    const int K = nvb * HID, J = K / 8;
+    float scale = 1.0f, inv_scale = 1.0f;
+    {
+        const unsigned mb = *dy_absmax;
+        const int e = (int)((mb >> 23) & 0xffu) - 127;
+        if (mb != 0u && e > -100 && e < 100) {
+            scale = __uint_as_float((unsigned)(127 + 13 - e) << 23);
+            inv_scale = __uint_as_float((unsigned)(127 - 13 + e) << 23);
+        }
+    }
+    if (tid < 64) {
+        long long s = tile * 64 + tid;
+        int offs[4];
+        float wgt[4];
+        const bool live = s < a.n_points;
+        if (!live) s = a.n_points - 1;
+        sample_taps(a, v, s, offs, wgt);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            tap_off[tid][k] = offs[k];
+            tap_w[tid][k] = live ? wgt[k] * inv_scale : 0.0f;   // the inverse scale rides on the tap weight
+        }
+    }
+    const float* dyv = dy_stash + tile * lay.dy_tile + (size_t)v * lay.dy_view;
+    auto stage_load = [&](int c, float4 (&sv)[2]) {
+        const int b = c / (HID / LG_KC), kg0 = (c % (HID / LG_KC)) * (LG_KC / 4);
+        const float4* src = reinterpret_cast<const float4*>(dyv + (size_t)(2 * b + 1) * STASH_SLOT) + (size_t)kg0 * 64;
+        sv[0] = src[tid];
+        sv[1] = src[tid + 256];
+    };
+    auto stage_store = [&](int buf, const float4 (&sv)[2]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint2 q0, q1;
+            lg_split2(sv[h].x * scale, sv[h].y * scale, q0.x, q1.x);
+            lg_split2(sv[h].z * scale, sv[h].w * scale, q0.y, q1.y);
+            bp[buf][0][4 * h + (tid >> 6)][tid & 63] = q0;
+            bp[buf][1][4 * h + (tid >> 6)][tid & 63] = q1;
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.f;
+    const int nt0 = nb * 8 + wave * 2;
+    const float4* wp = reinterpret_cast<const float4*>(w_cat) + (size_t)nt0 * J * 64 + lane;
+    const int nchunks = K / LG_KC;
+    float4 sv[2];
+    stage_load(0, sv);
+    stage_store(0, sv);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) stage_load(c + 1, sv);
+        float4 wa[LG_KC / 8][2];
+#pragma unroll
+        for (int j = 0; j < LG_KC / 8; ++j)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) wa[j][nt] = wp[((size_t)nt * J + (size_t)c * (LG_KC / 8) + j) * 64];
+#pragma unroll
+        for (int st_ = 0; st_ < LG_KC / 16; ++st_) {
+            // a 16-k step: the lane's own two float4 of the fp32 weight image (k = 16 s + 4 hh + 0..3 and 16 s + 8 + 4 hh + 0..3:
+            // which 8 k a fragment holds is free as long as both operands agree), split in registers
+            lgh8 a1[2], a2[2], b1[2], b2[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                uint4 u1, u2;
+                lg_split2(wa[2 * st_][nt].x, wa[2 * st_][nt].y, u1.x, u2.x);
+                lg_split2(wa[2 * st_][nt].z, wa[2 * st_][nt].w, u1.y, u2.y);
+                lg_split2(wa[2 * st_ + 1][nt].x, wa[2 * st_ + 1][nt].y, u1.z, u2.z);
+                lg_split2(wa[2 * st_ + 1][nt].z, wa[2 * st_ + 1][nt].w, u1.w, u2.w);
+                a1[nt] = __builtin_bit_cast(lgh8, u1);
+                a2[nt] = __builtin_bit_cast(lgh8, u2);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const uint2 l1 = bp[buf][0][4 * st_ + hh][32 * mt + m0], h1 = bp[buf][0][4 * st_ + 2 + hh][32 * mt + m0];
+                const uint2 l2 = bp[buf][1][4 * st_ + hh][32 * mt + m0], h2 = bp[buf][1][4 * st_ + 2 + hh][32 * mt + m0];
+                b1[mt] = __builtin_bit_cast(lgh8, make_uint4(l1.x, l1.y, h1.x, h1.y));
+                b2[mt] = __builtin_bit_cast(lgh8, make_uint4(l2.x, l2.y, h2.x, h2.y));
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[nt], b1[mt], acc[nt][mt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[nt], b1[mt], acc[nt][mt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[nt], b2[mt], acc[nt][mt], 0, 0, 0);
+        }
+        if (c + 1 < nchunks) {
+            stage_store(buf ^ 1, sv);
+            __syncthreads();
+        }
+    }
+    float* gv = grad + (size_t)v * a.Hl * a.Wl * a.L + 32 * nt0 + lane;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 t;
+                t.x = acc[nt][mt][4 * q + 0];
+                t.y = acc[nt][mt][4 * q + 1];
+                t.z = acc[nt][mt][4 * q + 2];
+                t.w = acc[nt][mt][4 * q + 3];
+                *reinterpret_cast<float4*>(&tr[wave][m0][32 * nt + 8 * q + 4 * hh]) = t;
+            }
+        __syncthreads();
+        for (int m = 0; m < 32; ++m) {
+            const float val = tr[wave][m][lane];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float wk = tap_w[32 * mt + m][k];
+                if (wk != 0.0f) unsafeAtomicAdd(gv + tap_off[32 * mt + m][k], wk * val);
+            }
+        }
+    }
+}
+
 void launch_latent_grad(const MlpArgs& a, const float* dy_stash, const StashLayout& lay, const float* w_cat, float* grad, int nvb,
-                        hipStream_t st) {
+                        hipStream_t st, const unsigned* dy_absmax) {
     const long long blocks = (long long)a.n_tiles * a.NS * (a.L / 256);
-    hipLaunchKernelGGL(latent_grad_kernel, dim3((unsigned)blocks), dim3(64 * LG_NW), 0, st, a, dy_stash, lay, w_cat, grad, nvb);
+    if (dy_absmax)
+        hipLaunchKernelGGL(latent_grad_h2_kernel, dim3((unsigned)blocks), dim3(64 * LG_NW), 0, st, a, dy_stash, lay, w_cat, grad, nvb, dy_absmax);
+    else
+        hipLaunchKernelGGL(latent_grad_kernel, dim3((unsigned)blocks), dim3(64 * LG_NW), 0, st, a, dy_stash, lay, w_cat, grad, nvb);
 }
 
 }  // namespace pny

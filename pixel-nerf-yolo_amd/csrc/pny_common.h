@@ -197,8 +197,9 @@ int mlp_pick_variant(long long n_points);           // shape for a launch of n_p
 void launch_mlp(const MlpArgs& a, int variant, int grid, hipStream_t st);
 void launch_mlp_stash(const MlpArgs& a, int grid, hipStream_t st);  // 8x64 shape, reference op order, writes a.stash_x
 // latent gradient (latent_grad.hip): a.tap_stride must be a.L; grad is (NS, Hl, Wl, L) channel-last, added into
+// dy_absmax (device word, the chain kernel's running max |dY|) selects the split-f16 kernel; null: fp32 MFMA
 void launch_latent_grad(const MlpArgs& a, const float* dy_stash, const StashLayout& lay, const float* w_cat, float* grad, int nvb,
-                        hipStream_t st);
+                        hipStream_t st, const unsigned* dy_absmax = nullptr);
 bool mlp_h2_supports(int n_blocks, int combine_layer);
 void launch_mlp_h2(const MlpArgs& a, int grid, hipStream_t st);
 void launch_mlp_h2s(const MlpArgs& a, int grid, hipStream_t st);   // mlp_h2s.hip: a.n_tiles in 32-sample tiles, grid <= 2 x CUs

@@ -450,7 +450,7 @@ int mlp_backward(pny_scene* s, int mode, const float* xyz, const float* dirs, co
         if (s->latent_grad && view_blocks(d) > 0) {
             if (!wt.wzT_cat) return fail(PNY_ERR_STATE, "latent gradient: transposed lin_z weights are missing");
             if (s->L % 256) return fail(PNY_ERR_ARG, "latent gradient: d_latent must be a multiple of 256");
-            launch_latent_grad(a, dy_base, plan.lay, wt.wzT_cat, s->latent_grad, view_blocks(d), st);
+            launch_latent_grad(a, dy_base, plan.lay, wt.wzT_cat, s->latent_grad, view_blocks(d), st, dw_h2 ? absmax : nullptr);
             PNY_HIP(hipGetLastError());
         }
         // 3. weight-gradient GEMMs over the two stashes + deterministic split reduction into the bound gradients

@@ -99,6 +99,8 @@ SIGNATURES = {
     "pny_scene_bind_latent_grad": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pny_scene_last_precision": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "pny_model_range_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint), C.c_int]),
+    "pny_trunk_train_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
+    "pny_trunk_train_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pny_scene_project": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pny_scene_last_mlp_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                            C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]),

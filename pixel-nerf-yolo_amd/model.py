@@ -353,10 +353,19 @@ class PixelNeRFNet(nn.Module):
                 check(L.pny_model_finalize(h))
                 self._enc_stale = False
                 self._dev_bound = True
+                self._trunk_bound = True
                 for name, t in self.state_dict(keep_vars=True).items():
                     if name.startswith("mlp_"):
                         ok = t.dtype == torch.float32 and t.is_contiguous() and t.device == dev
                         self._dev_bound = self._dev_bound and ok
+                        if ok:
+                            check(L.pny_model_bind_param(h, name.encode(), C.c_void_p(t.data_ptr())))
+                    elif name.startswith("encoder.model.") and not name.endswith("num_batches_tracked") \
+                            and not name.startswith(("encoder.model.layer4", "encoder.model.fc")):
+                        # the training-mode trunk (pny_trunk_train_forward / _backward) reads its parameters and steps the
+                        # running statistics where PyTorch keeps them
+                        ok = t.dtype == torch.float32 and t.is_contiguous() and t.device == dev
+                        self._trunk_bound = self._trunk_bound and ok
                         if ok:
                             check(L.pny_model_bind_param(h, name.encode(), C.c_void_p(t.data_ptr())))
             self._synced_key = key
@@ -644,7 +653,11 @@ class PixelNeRFNet(nn.Module):
         # its output enters like a supplied latent; the render backward returns d loss / d latent to that graph
         if (latent is None and not self.encoder.use_custom_resnet and torch.is_grad_enabled() and self.training
                 and not self.stop_encoder_grad and any(p.requires_grad for p in self.encoder.parameters())):
-            latent = self.encoder.forward_torch(images.to(dev, torch.float32))
+            if self._native_trunk_training():
+                tp = self._trunk_trainable()
+                latent = _TrunkFunction.apply(self, images.detach().to(dev, torch.float32).contiguous(), *[p for _, p in tp])
+            else:   # (batch norm modules in eval() mode under autograd, or parameters the library cannot read in place)
+                latent = self.encoder.forward_torch(images.to(dev, torch.float32))
         # a latent that requires grad (this trunk's, or a trainable encoder outside the library): the render backward returns
         # d loss / d latent for it (render._RenderFunction, pny_scene_bind_latent_grad)
         self._latent_src = latent if (torch.is_tensor(latent) and latent.requires_grad) else None
@@ -687,6 +700,30 @@ class PixelNeRFNet(nn.Module):
                 img = images[sb * NS:(sb + 1) * NS]
                 check(L.pny_scene_encode(s, ptr(img), NS, H, W, st))
         self.join_streams(streams)
+
+    # ---------------------------------------------------------------- encoder training on the library's trunk
+    def _trunk_bn_modules(self):
+        m = self.encoder.model
+        mods = [m.bn1]
+        for layer in (m.layer1, m.layer2, m.layer3):
+            for blk in layer:
+                mods += [blk.bn1, blk.bn2] + ([blk.downsample[1]] if hasattr(blk, "downsample") else [])
+        return mods
+
+    def _native_trunk_training(self):
+        """The training-mode trunk runs on the library's kernels (csrc/encoder_train.hip) when batch norm works on batch
+        statistics (every BatchNorm2d of the trunk in train() mode, momentum set, affine) and the parameters are readable in
+        place; PNYOLO_TRUNK=torch forces the ATen graph (SpatialEncoder.forward_torch)."""
+        if os.environ.get("PNYOLO_TRUNK", "native") == "torch" or not getattr(self, "_trunk_bound", False):
+            return False
+        bns = self._trunk_bn_modules()
+        return (all(b.momentum is not None and b.affine and b.track_running_stats for b in bns)
+                and len({bool(b.training) for b in bns}) == 1)     # all on batch statistics, or all on the running ones
+
+    def _trunk_trainable(self):
+        """(state_dict name, parameter) of the trunk parameters that take a gradient (layer4 / fc are not part of the trunk)."""
+        return [("encoder." + k, p) for k, p in self.encoder.named_parameters()
+                if p.requires_grad and k.startswith("model.") and not k.startswith(("model.layer4", "model.fc"))]
 
     def latent(self, sb=0):
         """(NS, L, Hl, Wl) latent of scene `sb` as the reference keeps it in encoder.latent."""
@@ -771,6 +808,74 @@ class PixelNeRFNet(nn.Module):
         if epochNum == "":
             torch.save(self.state_dict(), ckpt_path)
         return self
+
+
+class _TrunkFunction(torch.autograd.Function):
+    """The ResNet-34 trunk in training mode on the library's kernels (pny_trunk_train_forward / _backward, reference
+    src/model/encoder.py:139-173 under autograd): images (n, 3, H, W) -> latent (n, 512, H/2, W/2); backward fills the
+    gradients of the trainable trunk parameters.  Batch statistics, running statistics stepped as nn.BatchNorm2d does."""
+
+    @staticmethod
+    def forward(ctx, net, images, *params):
+        net._sync()
+        L = _lib.load()
+        dev = net._device()
+        n, _, H, W = images.shape
+        hl, wl = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+        lat = torch.empty(n, 512, hl, wl, device=dev, dtype=torch.float32)
+        bns = net._trunk_bn_modules()
+        bn_eval = not bns[0].training
+        check(L.pny_trunk_train_forward(net._h_model, ptr(images), n, H, W, float(bns[0].momentum), int(bn_eval), ptr(lat),
+                                        stream_of(dev)))
+        if not bn_eval:
+            with torch.no_grad():
+                for b in bns:
+                    b.num_batches_tracked += 1
+            net._enc_stale = True     # the inference trunk's folded batch norm is stale now (running statistics moved)
+        ctx.net = net
+        ctx.names = [k for k, _ in net._trunk_trainable()]
+        ctx.shapes = [tuple(p.shape) for p in params]
+        return lat
+
+    @staticmethod
+    def backward(ctx, d_lat):
+        net = ctx.net
+        L = _lib.load()
+        dev = net._device()
+        h = net._h_model
+        sizes = [int(np.prod(s)) for s in ctx.shapes]
+        offs = np.concatenate([[0], np.cumsum([(s + 63) // 64 * 64 for s in sizes])]).astype(np.int64)
+        d_lat = d_lat.detach().to(dev, torch.float32).contiguous()
+        # The trunk's backward needs d loss / d latent and nothing else of the renderer's backward: it runs on a stream of its
+        # own that starts behind the point where the latent gradient was complete (render._RenderFunction.backward records it
+        # in front of the MLPs' weight-gradient flush), beside that flush; the caller's stream takes it back at the end.
+        main = torch.cuda.current_stream(dev)
+        side = getattr(net, "_trunk_stream", None)
+        if os.environ.get("PNYOLO_TRUNK_STREAM", "1") == "0":
+            side = main
+        elif side is None or side.device != dev:
+            side = net._trunk_stream = torch.cuda.Stream(dev)
+        ev, net._lat_grad_event = getattr(net, "_lat_grad_event", None), None
+        if side is not main:
+            if ev is not None:
+                side.wait_event(ev)
+            else:
+                side.wait_stream(main)
+        with torch.cuda.stream(side):
+            flat = torch.zeros(int(offs[-1]), device=dev, dtype=torch.float32)
+            grads = [flat[int(o):int(o) + s].view(shp) for o, s, shp in zip(offs[:-1], sizes, ctx.shapes)]
+            for k, g in zip(ctx.names, grads):
+                check(L.pny_model_bind_grad(h, k.encode(), C.c_void_p(g.data_ptr())))
+            try:
+                check(L.pny_trunk_train_backward(h, ptr(d_lat), stream_of(dev)))
+            finally:
+                for k in ctx.names:
+                    check(L.pny_model_bind_grad(h, k.encode(), None))
+        if side is not main:
+            d_lat.record_stream(side)
+            flat.record_stream(main)
+            main.wait_stream(side)
+        return (None, None) + tuple(grads)
 
 
 class _QueryFunction(torch.autograd.Function):

@@ -286,9 +286,15 @@ class _RenderFunction(torch.autograd.Function):
                                             C.byref(gr), acc, stream_of(dev)))
         if deferred:
             model.join_streams(streams)
+        # d loss / d latent is complete here, BEFORE the weight-gradient flush is enqueued: the encoder's backward (the trunk's
+        # kernels, model._TrunkFunction) starts behind this point on its own stream and runs beside the flush
+        extra = () if lat_grad is None else (model.end_latent_grad(lat_grad, ctx.lat_meta, SB),)
+        if lat_grad is not None:
+            model._lat_grad_event = torch.cuda.Event()
+            model._lat_grad_event.record(torch.cuda.current_stream(dev))
+        if deferred:
             check(L.pny_model_flush_weight_grads(model._h_model, 1, stream_of(dev)))
             check(L.pny_model_defer_weight_grads(model._h_model, 0, 0, 0, 0))
-        extra = () if lat_grad is None else (model.end_latent_grad(lat_grad, ctx.lat_meta, SB),)
         return (None, None, None, None, None) + tuple(grads) + extra
 
 
