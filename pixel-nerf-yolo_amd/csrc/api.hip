@@ -1014,8 +1014,12 @@ static int run_mlp(pny_scene* s, int mode, const float* xyz, const float* dirs, 
         if (const char* e = getenv("PNYOLO_H2_SPLIT")) use_h2s = atoi(e) != 0;
     // wide shape (mlp_h2w.hip: 4 waves x 512 registers, 16 x 16 x 32 MFMAs): launches that give every CU more than one tile
     bool use_h2w = use_h2 && !use_h2s && mlp_h2w_supports(d.n_blocks, d.combine_layer) && h2w_default();
+    int h2w_mode = 1;   // 1: 4 waves x 512 registers (mlp_h2w.hip), 2: 8 waves x 256 (mlp_h2n.hip)
     if (use_h2 && !use_h2s)
-        if (const char* e = getenv("PNYOLO_H2_WIDE")) use_h2w = atoi(e) != 0 && mlp_h2w_supports(d.n_blocks, d.combine_layer);
+        if (const char* e = getenv("PNYOLO_H2_WIDE")) {
+            h2w_mode = atoi(e);
+            use_h2w = h2w_mode != 0 && mlp_h2w_supports(d.n_blocks, d.combine_layer);
+        }
     const int tm = use_h2s ? 32 : mlp_tile_samples(variant);
     const long long tiles = (n_points + tm - 1) / tm;
     if (tiles > 0x7fffffffll) return fail(PNY_ERR_ARG, "too many points for one launch");
@@ -1037,6 +1041,8 @@ static int run_mlp(pny_scene* s, int mode, const float* xyz, const float* dirs, 
     }
     if (use_h2s)
         launch_mlp_h2s(a, grid, st);
+    else if (use_h2w && h2w_mode == 2)
+        launch_mlp_h2n(a, grid, st);
     else if (use_h2w)
         launch_mlp_h2w(a, grid, st);
     else if (use_h2)

@@ -24,10 +24,26 @@ namespace pny {
 
 typedef float f32x4a __attribute__((ext_vector_type(4)));
 
+// The same source in a second shape (mlp_h2n.hip: -DPNY_HW_NW=8): EIGHT waves of 256 registers, two per SIMD like mlp_h2.hip, a wave
+// owning 64 features (4 x 4 tiles of 16 x 16) -- the 16 x 16 x 32 MFMA, its conflict-free plane writes and the n-tile-major
+// weight refetch in the occupancy of the product kernel.
+#ifndef PNY_HW_NW
+#define PNY_HW_NW 4
+#endif
+#if PNY_HW_NW == 4
+#define PNY_HW_KERNEL pny_mlp_h2w_kernel
+#define PNY_HW_LAUNCH launch_mlp_h2w
+#define PNY_HW_STAMPBUF PNY_HW_STAMPBUF
+#else
+#define PNY_HW_KERNEL pny_mlp_h2n_kernel
+#define PNY_HW_LAUNCH launch_mlp_h2n
+#define PNY_HW_STAMPBUF g_h2n_stamp_buf
+#endif
+
 // Diagnostic build only (-DPNY_H2_STAMP): s_memtime brackets around the phases of a tile (as in mlp_h2.hip)
 #ifdef PNY_H2_STAMP
 enum { HS_TOTAL = 0, HS_GEMM, HS_GATHER_WAIT, HS_GATHER, HS_EPI_WAIT, HS_EPI, HS_PROLOGUE, HS_LINOUT, HS_SLAB, HS_REAL, HS_N };
-__device__ unsigned long long* g_h2w_stamp_buf;
+__device__ unsigned long long* PNY_HW_STAMPBUF;
 __device__ __forceinline__ unsigned long long hwnow() {
     unsigned long long t;
     __builtin_amdgcn_sched_barrier(0);
@@ -48,8 +64,11 @@ __device__ __forceinline__ unsigned long long hwnow() {
 #endif
 
 namespace hw {
-constexpr int NW = 4, THREADS = 64 * NW, TM = 64;
-constexpr int NT = 8, MT = 4;                 // 16 x 16 accumulator tiles per wave: 128 features x 64 samples
+constexpr int NW = PNY_HW_NW, THREADS = 64 * NW, TM = 64;
+constexpr int NT = 32 / NW, MT = 4;           // 16 x 16 accumulator tiles per wave: (512 / NW) features x 64 samples
+constexpr int FPG = 8 / NT;                   // next-step B fragments read per n-tile group
+constexpr int SPW = 8 / NW;                   // 8-sample blocks a wave serves in the gather
+static_assert(NW == 4 || NW == 8, "shape");
 constexpr int ROW_BYTES = TM * 16;            // one plane of one row (8 features x TM samples x f16)
 constexpr int ACT_BYTES = 64 * 2 * ROW_BYTES; // [row = feature / 8][plane][sample] x 16 bytes = 128 KiB
 constexpr int TAP_BYTES = 32 * TM;
@@ -76,11 +95,14 @@ __device__ __forceinline__ h8 hwload(const WStream& ws, unsigned seg_off, int nt
 // fetch that misses L2 (7 % of them do, served by the Infinity Cache at 2-3x the latency): with RD = 1 a fragment is
 // refetched 7/8 of a step (1.3 k cycles) before its next use and the GEMM phases run the matrix pipe at 78 %; RD = 2 gives
 // 15/8 of a step for 64 more registers.
+#ifndef PNY_HW_PF
+#define PNY_HW_PF 0   // gather pieces of the next block fetched underneath the fc_1 GEMM (8-wave shape).  Measured: 0 -> 39.5, 1 -> 43.6, 2 -> 47.8, 4 -> 53.7 ms per launch (130 / 230 / 298 spilled registers, some inside the GEMM loops)
+#endif
 #ifndef PNY_HW_RD
-#define PNY_HW_RD 2
+#define PNY_HW_RD 1   // (2 measured on the 4-wave shape: 52.2 vs 46.2 ms per launch -- 509 spilled registers)
 #endif
 #ifndef PNY_HW_GD
-#define PNY_HW_GD 3   // gather pieces (32 registers each) in flight
+#define PNY_HW_GD (PNY_HW_NW == 4 ? 3 : 4)   // gather pieces (16 registers per sample block served) in flight
 #endif
 struct HwRing {
     h8 f[PNY_HW_RD][hw::NT][2];   // slot d holds step j + d at the head of step j (rotating statically: steps are unrolled by 2)
@@ -117,13 +139,17 @@ __device__ __forceinline__ void hwstep(f32x4a (&acc)[hw::NT][hw::MT], HwRing& r,
         for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(r.f[D][nt][0], B[mt][1], acc[nt][mt], 0, 0, 0);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(r.f[D][nt][1], B[mt][0], acc[nt][mt], 0, 0, 0);
-        // one of the next step's 8 activation fragments per n-tile group
-        Bn[nt >> 1][nt & 1] = *reinterpret_cast<const h8*>(bnext + (nt & 1) * ROW_BYTES + (nt >> 1) * 256);
+        // the next step's 8 activation fragments, FPG per n-tile group
+#pragma unroll
+        for (int i = 0; i < FPG; ++i) {
+            const int f = nt * FPG + i;
+            Bn[f >> 1][f & 1] = *reinterpret_cast<const h8*>(bnext + (f & 1) * ROW_BYTES + (f >> 1) * 256);
+        }
         r.f[D][nt][0] = hwload(ws, src, nt, 0, jx);
         r.f[D][nt][1] = hwload(ws, src, nt, 1, jx);
 #ifndef PNY_H2_NOSCHED
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, FPG, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
         __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
 #endif
@@ -131,9 +157,15 @@ __device__ __forceinline__ void hwstep(f32x4a (&acc)[hw::NT][hw::MT], HwRing& r,
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// acc += W_slice . act over segment `cur` (an even number of steps); leaves the ring holding the first RD steps of `next`
+// acc += W_slice . act over segment `cur` (an even number of steps); leaves the ring holding the first RD steps of `next`.
+// `side`: loads whose results are needed AFTER this GEMM (the next block's first gather pieces), issued from inside the loop --
+// placed in front of it the compiler sinks them behind the loop, to their first use (mlp_h2.hip h2gemm).
+struct HwNoSide {
+    __device__ __forceinline__ void operator()() const {}
+};
+template <class Side = HwNoSide>
 __device__ __forceinline__ void hwgemm(f32x4a (&acc)[hw::NT][hw::MT], HwRing& r, const WStream& ws, const HwSeg& cur, const HwSeg& next,
-                                       const char* planes, int lane) {
+                                       const char* planes, int lane, Side side = Side()) {
     using namespace hw;
     constexpr int RD = PNY_HW_RD;
     const char* bp = planes + (lane >> 4) * (2 * ROW_BYTES) + (lane & 15) * 16;   // row 4 j + (lane >> 4), plane 0, sample lane & 15
@@ -144,6 +176,7 @@ __device__ __forceinline__ void hwgemm(f32x4a (&acc)[hw::NT][hw::MT], HwRing& r,
 #pragma unroll
         for (int p = 0; p < 2; ++p) B0[mt][p] = *reinterpret_cast<const h8*>(bp + p * ROW_BYTES + mt * 256);
     for (int j = 0; j < jn; j += 2) {
+        if (j == 2) side();
         // step j consumes slot 0 (RD = 1) / slot 0 (RD = 2) and refetches it with step j + RD; step j + 1 the other way round
         const int ja = j + RD, jb = j + 1 + RD;
         const bool ina = ja < jn, inb = jb < jn;
@@ -162,8 +195,8 @@ __device__ __forceinline__ void hwepilogue(f32x4a (&acc)[hw::NT][hw::MT], const 
                                            unsigned* range_flag) {
     using namespace hw;
     const int fq = lane >> 4;
-    const float* bl = bias + 128 * wave + 4 * fq;
-    char* base = planes + (16 * wave + (fq >> 1)) * (2 * ROW_BYTES) + (lane & 15) * 16 + 8 * (fq & 1);
+    const float* bl = bias + 16 * NT * wave + 4 * fq;
+    char* base = planes + (2 * NT * wave + (fq >> 1)) * (2 * ROW_BYTES) + (lane & 15) * 16 + 8 * (fq & 1);
     float rmax = 0.f;   // f16-range guard (include/pnyolo.h pny_model_range_status)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -226,14 +259,14 @@ __device__ __forceinline__ void hwslab_load(f32x4a (&t)[hw::NT][hw::MT], const H
 // from the tap table at every block (24 registers that would otherwise stay live across the GEMMs), and moves one line of
 // both per piece: 8 tap loads of 16 bytes = 32 registers, pieces in flight as the caller chooses.
 struct HwTaps {
-    const float* t[2][4];
-    float w[2][4];
+    const float* t[hw::SPW][4];
+    float w[hw::SPW][4];
 };
 __device__ __forceinline__ void hwgather_setup(HwTaps& g, const float* view_base, const float4* tap_tab, int wave, int lane) {
     const float* base = view_base + 4 * (lane >> 3);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = (2 * wave + i) * 8 + (lane & 7);
+    for (int i = 0; i < hw::SPW; ++i) {
+        const int m = (hw::SPW * wave + i) * 8 + (lane & 7);
         const float4 o = tap_tab[2 * m], w = tap_tab[2 * m + 1];
         g.t[i][0] = base + __float_as_int(o.x);
         g.t[i][1] = base + __float_as_int(o.y);
@@ -246,11 +279,11 @@ __device__ __forceinline__ void hwgather_setup(HwTaps& g, const float* view_base
     }
 }
 struct HwPiece {
-    float4 x[2][4];   // [sample][tap]
+    float4 x[hw::SPW][4];   // [sample][tap]
 };
 __device__ __forceinline__ void hwgather_issue(HwPiece& pc, const HwTaps& g, int c0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < hw::SPW; ++i)
 #pragma unroll
         for (int k = 0; k < 4; ++k) pc.x[i][k] = *reinterpret_cast<const float4*>(g.t[i][k] + c0);
 }
@@ -258,8 +291,8 @@ __device__ __forceinline__ void hwgather_issue(HwPiece& pc, const HwTaps& g, int
 __device__ __forceinline__ void hwgather_commit(const HwPiece& pc, const HwTaps& g, char* planes, int ln, int wave, int lane) {
     using namespace hw;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = (2 * wave + i) * 8 + (lane & 7);
+    for (int i = 0; i < SPW; ++i) {
+        const int m = (SPW * wave + i) * 8 + (lane & 7);
         const float4(&x)[4] = pc.x[i];
         const float(&w)[4] = g.w[i];
         float2 lo, hi;
@@ -338,7 +371,7 @@ __device__ __forceinline__ void hwprologue(const MlpArgs& a, int v, long long ti
     }
 }
 
-__global__ __launch_bounds__(hw::THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void pny_mlp_h2w_kernel(const MlpArgs a) {
+__global__ __launch_bounds__(hw::THREADS) __attribute__((amdgpu_waves_per_eu(hw::NW / 4, hw::NW / 4))) void PNY_HW_KERNEL(const MlpArgs a) {
     using namespace hw;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     char* planes = smem_raw;
@@ -380,7 +413,12 @@ __global__ __launch_bounds__(hw::THREADS) __attribute__((amdgpu_waves_per_eu(1, 
         f32x4a h[NT][MT];
         f32x4a net[NT][MT];
         // one residual block from "planes hold relu(h_in)" on: net = fc_0(.), h += fc_1(relu(net + b_fc0))
-        auto block_tail = [&](int blk, const HwSeg& after, bool slab_in) {
+        // PREFETCH (8-wave shape): the first PNY_HW_GD pieces of the NEXT block's projection are fetched underneath the fc_1 GEMM, in
+        // the registers of the then-dead `net` accumulators (16 registers a piece); the tap pointers are set up per view.
+        constexpr bool PREFETCH = NW == 8 && PNY_HW_PF > 0;
+        HwPiece pc[PNY_HW_GD];
+        const float* zp_view = a.zp;   // (set per view below)
+        auto block_tail = [&](int blk, const HwSeg& after, bool slab_in, int next_cb = -1) {
             HS_T0();
             hwzero(net);
             __syncthreads();
@@ -401,6 +439,18 @@ __global__ __launch_bounds__(hw::THREADS) __attribute__((amdgpu_waves_per_eu(1, 
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) h[nt][mt] = net[nt][mt] + h[nt][mt];
+            } else if (PREFETCH && next_cb >= 0) {
+                HS_LAP(HS_EPI);
+                __syncthreads();
+                HS_LAP(HS_EPI_WAIT);
+                hwgemm(h, ring, ws, fc1seg(blk), after, planes, lane, [&]() {
+                    HwTaps gp;   // (the tap pointers are re-read from the table here and again in the gather phase: kept across
+                                 // the GEMMs they cost 12 registers where the loops have none to spare)
+                    hwgather_setup(gp, zp_view, tap_tab, wave, lane);
+#pragma unroll
+                    for (int i = 0; i < PNY_HW_PF; ++i) hwgather_issue(pc[i], gp, next_cb + 32 * i);
+                });
+                HS_LAP(HS_GEMM);
             } else {
                 HS_LAP(HS_EPI);
                 __syncthreads();
@@ -416,26 +466,44 @@ __global__ __launch_bounds__(hw::THREADS) __attribute__((amdgpu_waves_per_eu(1, 
             hwprologue(a, v, tile, planes, tap_tab, tid);
             hwzero(h);
             __syncthreads();
+            zp_view = a.zp + (size_t)v * a.Hl * a.Wl * a.zp_stride;
+            if (PREFETCH) {   // block 0's first pieces travel underneath the lin_in GEMM
+                HwTaps gp;
+                hwgather_setup(gp, zp_view, tap_tab, wave, lane);
+#pragma unroll
+                for (int i = 0; i < PNY_HW_PF; ++i) hwgather_issue(pc[i], gp, 32 * i);
+            }
             HS_LAP(HS_PROLOGUE);
             hwgemm(h, ring, ws, s_in, fc0seg(0), planes, lane);
             HS_LAP(HS_GEMM);
             for (int blk = 0; blk < nvb; ++blk) {
                 // h += interp(lin_z[blk](latent map)): the block's 512 projected channels in 16 pieces of 32 (one 128-byte line
-                // per tap and sample), four in flight
+                // per tap and sample), PNY_HW_GD in flight
                 const int cb = blk * HID;
-                HwTaps g;
-                HwPiece pc[PNY_HW_GD];
                 HS_T0();
                 __syncthreads();  // every wave is done reading the planes (previous GEMM)
                 HS_LAP(HS_GATHER_WAIT);
-                hwgather_setup(g, a.zp + (size_t)v * a.Hl * a.Wl * a.zp_stride, tap_tab, wave, lane);
+                HwTaps g;
+                hwgather_setup(g, zp_view, tap_tab, wave, lane);
+                if (PREFETCH) {
 #pragma unroll
-                for (int i = 0; i < PNY_HW_GD - 1; ++i) hwgather_issue(pc[i], g, cb + 32 * i);
-#pragma unroll
-                for (int ln = 0; ln < 16; ++ln) {
-                    if (ln + PNY_HW_GD - 1 < 16) hwgather_issue(pc[(ln + PNY_HW_GD - 1) % PNY_HW_GD], g, cb + 32 * (ln + PNY_HW_GD - 1));
+                    for (int i = PNY_HW_PF; i < PNY_HW_GD; ++i) hwgather_issue(pc[i], g, cb + 32 * i);
                     __builtin_amdgcn_sched_barrier(0);
-                    hwgather_commit(pc[ln % PNY_HW_GD], g, planes, ln, wave, lane);
+#pragma unroll
+                    for (int ln = 0; ln < 16; ++ln) {   // pieces 0 .. GD - 1 are in flight: commit, then refill the slot
+                        hwgather_commit(pc[ln % PNY_HW_GD], g, planes, ln, wave, lane);
+                        if (ln + PNY_HW_GD < 16) hwgather_issue(pc[ln % PNY_HW_GD], g, cb + 32 * (ln + PNY_HW_GD));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < PNY_HW_GD - 1; ++i) hwgather_issue(pc[i], g, cb + 32 * i);
+#pragma unroll
+                    for (int ln = 0; ln < 16; ++ln) {
+                        if (ln + PNY_HW_GD - 1 < 16) hwgather_issue(pc[(ln + PNY_HW_GD - 1) % PNY_HW_GD], g, cb + 32 * (ln + PNY_HW_GD - 1));
+                        __builtin_amdgcn_sched_barrier(0);
+                        hwgather_commit(pc[ln % PNY_HW_GD], g, planes, ln, wave, lane);
+                    }
                 }
                 HS_LAP(HS_GATHER);
                 __syncthreads();  // projection visible
@@ -443,7 +511,7 @@ __global__ __launch_bounds__(hw::THREADS) __attribute__((amdgpu_waves_per_eu(1, 
                 hwepilogue<true>(h, entry_bias(blk), planes, wave, lane, a.range_flag);
                 HS_LAP(HS_EPI);
                 const bool last = blk + 1 == nvb;
-                block_tail(blk, last ? after_view : fc0seg(blk + 1), last && v > 0);
+                block_tail(blk, last ? after_view : fc0seg(blk + 1), last && v > 0, last ? -1 : cb + HID);
             }
             if (a.NS > 1) {
                 if (v + 1 < a.NS) {
@@ -504,19 +572,21 @@ __global__ __launch_bounds__(hw::THREADS) __attribute__((amdgpu_waves_per_eu(1, 
     hs_acc[HS_TOTAL] = hwnow() - hs_start;
     hs_acc[HS_REAL] = __builtin_amdgcn_s_memrealtime() - hs_real0;
     if (lane == 0)
-        for (int i = 0; i < HS_N; ++i) g_h2w_stamp_buf[((size_t)blockIdx.x * NW + wave) * HS_N + i] = hs_acc[i];
+        for (int i = 0; i < HS_N; ++i) PNY_HW_STAMPBUF[((size_t)blockIdx.x * NW + wave) * HS_N + i] = hs_acc[i];
 #endif
 }
 
+#if PNY_HW_NW == 4
 bool mlp_h2w_supports(int n_blocks, int combine_layer) { return n_blocks <= hw::MAX_NB && combine_layer >= 1; }
+#endif
 
-void launch_mlp_h2w(const MlpArgs& a, int grid, hipStream_t st) {
+void PNY_HW_LAUNCH(const MlpArgs& a, int grid, hipStream_t st) {
     static bool attr_set[64] = {};
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
     dev_ &= 63;
     if (!attr_set[dev_]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pny_mlp_h2w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(PNY_HW_KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   hw::lds_bytes(hw::MAX_NB));
         attr_set[dev_] = true;
     }
@@ -525,11 +595,11 @@ void launch_mlp_h2w(const MlpArgs& a, int grid, hipStream_t st) {
     const size_t nst = (size_t)grid * hw::NW * HS_N;
     if (!dbuf) {
         (void)hipMalloc((void**)&dbuf, (size_t)1024 * 8 * HS_N * sizeof(unsigned long long));
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_h2w_stamp_buf), &dbuf, sizeof(dbuf));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(PNY_HW_STAMPBUF), &dbuf, sizeof(dbuf));
     }
     (void)hipMemsetAsync(dbuf, 0, nst * sizeof(unsigned long long), st);
 #endif
-    hipLaunchKernelGGL(pny_mlp_h2w_kernel, dim3(grid), dim3(hw::THREADS), hw::lds_bytes(a.n_blocks), st, a);
+    hipLaunchKernelGGL(PNY_HW_KERNEL, dim3(grid), dim3(hw::THREADS), hw::lds_bytes(a.n_blocks), st, a);
 #ifdef PNY_H2_STAMP
     {
         std::vector<unsigned long long> hst(nst);
@@ -538,7 +608,7 @@ void launch_mlp_h2w(const MlpArgs& a, int grid, hipStream_t st) {
         double sum[HS_N] = {0};
         for (size_t i = 0; i < nst; ++i) sum[i % HS_N] += (double)hst[i];
         static const char* names[HS_N] = {"total", "gemm", "gather-barrier-wait", "gather", "epilogue-barrier-wait", "epilogue", "prologue", "lin_out", "slab", "realtime"};
-        fprintf(stderr, "[h2w stamp] tiles=%d grid=%d:", a.n_tiles, grid);
+        fprintf(stderr, "[h2w stamp, %d waves] tiles=%d grid=%d:", hw::NW, a.n_tiles, grid);
         for (int i = 0; i < HS_N; ++i) fprintf(stderr, " %s=%.1f%%", names[i], 100.0 * sum[i] / sum[0]);
         fprintf(stderr, " (mean wave cycles %.4g; in-kernel clock %.3f GHz)\n", sum[0] / ((double)grid * hw::NW), sum[0] / sum[HS_REAL] * 0.1);
     }

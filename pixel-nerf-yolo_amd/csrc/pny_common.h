@@ -205,6 +205,7 @@ void launch_mlp_h2(const MlpArgs& a, int grid, hipStream_t st);
 void launch_mlp_h2s(const MlpArgs& a, int grid, hipStream_t st);   // mlp_h2s.hip: a.n_tiles in 32-sample tiles, grid <= 2 x CUs
 void launch_mlp_h2_stash(const MlpArgs& a, int grid, hipStream_t st);   // + the backward's operand stash (a.stash_x, a.lay)     // 8x64 shape, projected latent, split-f16 operands (mlp_h2.hip)
 bool mlp_h2w_supports(int n_blocks, int combine_layer);
+void launch_mlp_h2n(const MlpArgs& a, int grid, hipStream_t st);   // mlp_h2n.hip: the same kernel as 8 waves x 256 registers
 void launch_mlp_h2w(const MlpArgs& a, int grid, hipStream_t st);   // mlp_h2w.hip: 4 waves x 512 registers, needs a.h3_*; 64-sample tiles
 int mlp_max_grid(int variant);      // resident workgroups = persistent grid size
 int mlp_tile_samples(int variant);  // samples per workgroup tile (32 or 64)
