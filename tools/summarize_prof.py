@@ -65,6 +65,27 @@ def main(tag):
             a[1] += float(r["Counter_Value"])
         for cname, a in sorted(acc.items()):
             out.append(f"| {os.path.basename(p)} | {cname} | {a[1]/max(a[0],1):.6g} | {a[0]} |")
+    # ---- derived: the clock the chip held and the matrix pipe's busy fraction (profiles/r03_kernel_experiments.md section 1)
+    vals = {}
+    for p in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+        acc2 = defaultdict(lambda: [0, 0.0])
+        for r in frame_rows(os.path.join(p, "**", "*counter_collection.csv")):
+            a = acc2[r["Counter_Name"]]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+        for k, a in acc2.items():
+            vals[k] = a[1] / max(a[0], 1)
+    if frame and "GRBM_GUI_ACTIVE" in vals and "SQ_VALU_MFMA_BUSY_CYCLES" in vals:
+        avg_ms = sum(dur_ms(r) for r in frame) / len(frame)
+        cyc = vals["GRBM_GUI_ACTIVE"] / 8.0
+        busy = vals["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc)
+        out.append("\n## Derived (one formula, profiles/r03_kernel_experiments.md section 1)\n")
+        out.append("* cycles per launch = GRBM_GUI_ACTIVE / 8 XCDs = %.4g; sustained clock = cycles / %.3f ms (kernel trace, full-frame "
+                   "launches) = **%.2f GHz** (profiled passes run 1-3 %% off the plain run)" % (cyc, avg_ms, cyc / avg_ms / 1e6))
+        out.append("* matrix-busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x cycles) = %.4g / (1024 x %.4g) = **%.3f**" %
+                   (vals["SQ_VALU_MFMA_BUSY_CYCLES"], cyc, busy))
+        out.append("* roofline.frac = matrix-busy x clock / 2.4 GHz = %.3f (the bench line's `frac` from HIP events measures the same thing)"
+                   % (busy * cyc / avg_ms / 1e6 / 2.4))
     os.makedirs("profiles", exist_ok=True)
     # fabric-side bytes per MLP launch for bench.py's roofline.traffic (MI355X_MICROARCH.md, HBM section:
     # (FETCH_SIZE + WRITE_SIZE) KB, FETCH_SIZE doubled on gfx950 for 16-B/lane streaming reads; the
