@@ -260,9 +260,18 @@ def train_main(args):
             dist.barrier()
         torch.cuda.synchronize()
 
+    if os.environ.get("PNYOLO_BENCH_NO_GC"):   # diagnostic: is the periodic slow step the collector?
+        import gc
+        gc.disable()
     for i in range(max(args.warmup, 4)):
         l0 = step(i)
     fence()
+    # Everything allocated so far (modules, synthetic arrays, compiled signatures) lives for the whole run: move it out of the
+    # collector's generations, or a full collection walks it in the middle of the timed steps (measured: one step in ~15 took
+    # 80-110 ms instead of 12.7 -- PNYOLO_BENCH_NO_GC=1 removes the step, this keeps the collector on)
+    import gc
+    gc.collect()
+    gc.freeze()
     net.enable_kernel_timing(True)
     k_ms, k_fl = [0.0] * 4, [0.0] * 4
     prof = None
