@@ -366,7 +366,10 @@ typedef struct pny_render_grads {
     const float* weights_fine;
 } pny_render_grads;
 /* Backward of pny_render for one scene: composite backward + MLP backward of the fine pass (mlp_fine) and of the coarse
- * pass (mlp_coarse), into the bound gradients (accumulate as above; with one shared MLP the two passes add up). */
+ * pass (mlp_coarse), into the bound gradients (accumulate as above; with one shared MLP the two passes add up).
+ * accumulate bit 4: only the fine pass of this backward; bit 8: only the coarse pass (call with bit 4 first: the coarse
+ * pass takes the depth-sample path's gradient the fine pass left in the scene) -- lets a caller put mlp_fine's
+ * weight-gradient flush (pny_model_flush_weight_grads with bit 32) between the two. */
 int pny_render_backward(pny_scene* s, const float* rays_dev, int64_t n, const pny_render_opts* opts,
                         const pny_render_saved* saved, const pny_render_grads* grads, int accumulate, pny_stream stream);
 
@@ -389,7 +392,7 @@ int pny_model_defer_weight_grads(pny_model* m, int enable, int ns, int64_t coars
  * MLP passes with the stashing instantiation (reference operation order; rgb / sigma within fp32 rounding of the
  * projected evaluation) directly into the reservation; the pny_render_backward that follows (same reservation, z_* /
  * sample_* of that forward given in pny_render_saved) then skips its forward recompute and starts at the dX chain.
- * One-shot: the flag clears itself; a pass that does not fit the reservation runs the plain forward. */
+ * One-shot: the flag clears itself; a pass that does not fit the reservation runs the plain forward.  * accumulate bit 16: flush mlp_coarse's stash only; bit 32: mlp_fine's only (0: both, mlp_coarse first). */
 int pny_scene_stash_next_render(pny_scene* s, int enable);
 int pny_model_flush_weight_grads(pny_model* m, int accumulate, pny_stream stream);
 /* GEMM FLOPs and HIP-event time of the last flush. */

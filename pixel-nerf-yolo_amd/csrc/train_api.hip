@@ -513,15 +513,21 @@ int pny_model_flush_weight_grads(pny_model* m, int accumulate, pny_stream stream
     PNY_HIP(hipSetDevice(m->desc.device));
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    m->flush_flops = 0.0;
-    m->flush_launches = 0;
+    if (!(accumulate & 16)) {   // (a coarse-only flush follows the fine-only one of the same step: keep its numbers)
+        m->flush_flops = 0.0;
+        m->flush_launches = 0;
+    }
     for (int i = 0; i < 4; ++i)
         if (!m->flush_ev[i]) PNY_HIP(hipEventCreate(&m->flush_ev[i]));
     const pny_model_desc& d = m->desc;
     const int nvb_ = view_blocks(d), npost_ = d.n_blocks - nvb_, d_in_ = 3 + 6 * d.num_freqs + 3;
     const double per_view_f = (double)d_in_ * HID + (double)nvb_ * d.d_latent * HID + 2.0 * nvb_ * HID * HID;
     const double fwd = 2.0 * (m->defer_ns * per_view_f + 2.0 * npost_ * HID * HID + (double)HID * d.d_out);
+    // bits 16 / 32 of `accumulate`: only mlp_coarse's / only mlp_fine's stash (0: both)
+    const bool only_c = (accumulate & 16) != 0, only_f = (accumulate & 32) != 0;
+    accumulate &= 1;
     for (int w = 0; w < 2; ++w) {
+        if ((w == 0 && only_f) || (w == 1 && only_c)) continue;
         PNY_HIP(hipEventRecord(m->flush_ev[2 * w], st));
         if (m->defer_used[w] > 0) {
             TrainPlan plan = build_plan(m, m->defer_ns, d.d_latent, w ? "mlp_fine." : "mlp_coarse.");
@@ -534,9 +540,10 @@ int pny_model_flush_weight_grads(pny_model* m, int accumulate, pny_stream stream
         }
         PNY_HIP(hipEventRecord(m->flush_ev[2 * w + 1], st));
         m->defer_used[w] = 0;
+        if (m->d_absmax.p)   // the next step's chains start from 0
+            PNY_HIP(hipMemsetAsync(reinterpret_cast<unsigned*>(m->d_absmax.p) + w, 0, sizeof(unsigned), st));
     }
-    if (m->d_absmax.p) PNY_HIP(hipMemsetAsync(m->d_absmax.p, 0, 2 * sizeof(unsigned), st));   // the next step's chains start from 0
-    m->defer_dw_f32 = false;
+    if (!only_f) m->defer_dw_f32 = false;   // (a fine-only flush is followed by the coarse-only one of the same step)
     return PNY_OK;
 }
 
@@ -608,6 +615,9 @@ int pny_render_backward(pny_scene* s, const float* rays_dev, int64_t n, const pn
     if ((rc = s->d_samp.reserve((size_t)n * kt * 4 * sizeof(float)))) return rc;
     const bool same_mlp = !s->m->desc.has_fine || !s->m->use_fine;  // both passes differentiate mlp_coarse
     const bool immediate = (accumulate & 2) != 0;   // ignore a deferred reservation that belongs to another forward
+    // bits 4 / 8: only the fine / only the coarse pass of this backward (the caller runs every scene's fine pass, starts the
+    // fine MLP's weight-gradient flush beside the coarse passes, then the coarse passes: pny_model_flush_weight_grads)
+    const bool do_fine = (accumulate & 8) == 0, do_coarse = (accumulate & 4) == 0;
     bool first = true;
     const bool any_f = o->n_fine > 0 && (g->rgb_fine || g->depth_fine || g->weights_fine);
     const bool any_c = g->rgb_coarse || g->depth_coarse || g->weights_coarse;
@@ -624,11 +634,15 @@ int pny_render_backward(pny_scene* s, const float* rays_dev, int64_t n, const pn
                 PNY_HIP(hipMemsetAsync(m->ddy_stash[sp.which].f() + sp.tile0 * dy_tile, 0, (size_t)sp.tiles * dy_tile * sizeof(float), st));
             return 0;
         };
-        if (!any_f && (rc = zero_pass(s->stashed[1]))) return rc;
-        if (!(any_c || depth_path) && (rc = zero_pass(s->stashed[0]))) return rc;
+        if (do_fine && !any_f && (rc = zero_pass(s->stashed[1]))) return rc;
+        if (do_coarse && !(any_c || depth_path) && (rc = zero_pass(s->stashed[0]))) return rc;
     }
     const float* g_depth_c = g->depth_coarse;
-    if (any_f) {
+    if (any_f && !do_fine) {   // coarse-only call: the fine pass of this backward ran in an earlier call and left the depth path's sum
+        if (depth_path) g_depth_c = s->gdepth_tmp.f();
+        first = false;
+    }
+    if (any_f && do_fine) {
         float* dz = nullptr;
         int* sel = nullptr;
         if (depth_path) {
@@ -652,7 +666,7 @@ int pny_render_backward(pny_scene* s, const float* rays_dev, int64_t n, const pn
         }
         first = false;
     }
-    if (any_c || depth_path) {
+    if (do_coarse && (any_c || depth_path)) {
         launch_composite_bwd(rays_dev, sv->z_coarse, sv->sample_coarse, o->sigma_noise_coarse_dev, n, kc, o->white_bkgd, g->rgb_coarse,
                              g_depth_c, g->weights_coarse, s->d_samp.f(), nullptr, st);
         PNY_HIP(hipGetLastError());

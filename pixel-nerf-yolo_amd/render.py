@@ -15,6 +15,7 @@ in the fine pass -- they are inputs of the path.  By default a per-call Philox s
 explicit tensors instead (parity mode, consumed by the next call).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -273,17 +274,44 @@ class _RenderFunction(torch.autograd.Function):
         # with atomics from their own streams, and nothing else would order those behind the fill.
         lat_grad = model.begin_latent_grad(ctx.lat_meta, SB) if ctx.lat_meta is not None else None
         streams = model.fork_streams(SB) if deferred else [None] * SB
+        calls = []
         for sb in range(SB):
+            s_ = _lib.RenderSaved(z_coarse=sv["z_coarse"][sb].data_ptr(), sample_coarse=sv["sample_coarse"][sb].data_ptr())
+            if not getattr(ren, "_detach_fine_depth", False):   # test aid: treat the depth samples as constants
+                s_.depth_coarse = sv["depth_coarse"][sb].data_ptr()
+            if ctx.has_fine:
+                s_.z_fine = sv["z_fine"][sb].data_ptr()
+                s_.sample_fine = sv["sample_fine"][sb].data_ptr()
+            calls.append((s_, _lib.RenderGrads(*[None if p is None else p[sb].data_ptr() for p in ups])))
+
+        def run(sb, bits):
             with torch.cuda.stream(streams[sb]):
-                s_ = _lib.RenderSaved(z_coarse=sv["z_coarse"][sb].data_ptr(), sample_coarse=sv["sample_coarse"][sb].data_ptr())
-                if not getattr(ren, "_detach_fine_depth", False):   # test aid: treat the depth samples as constants
-                    s_.depth_coarse = sv["depth_coarse"][sb].data_ptr()
-                if ctx.has_fine:
-                    s_.z_fine = sv["z_fine"][sb].data_ptr()
-                    s_.sample_fine = sv["sample_fine"][sb].data_ptr()
-                gr = _lib.RenderGrads(*[None if p is None else p[sb].data_ptr() for p in ups])
-                check(L.pny_render_backward(model._scene(sb), ptr(sv["rays"][sb]), B, C.byref(sv["opts"][sb]), C.byref(s_),
-                                            C.byref(gr), acc, stream_of(dev)))
+                check(L.pny_render_backward(model._scene(sb), ptr(sv["rays"][sb]), B, C.byref(sv["opts"][sb]), C.byref(calls[sb][0]),
+                                            C.byref(calls[sb][1]), acc | bits, stream_of(dev)))
+        # Optional (PNYOLO_SPLIT_FLUSH=1): every scene's FINE pass first, then mlp_fine's weight-gradient flush on a stream of its own
+        # BESIDE the coarse passes instead of behind them.  Measured (round 3): no gain -- 12.5-13.5 ms per step against 12.3-12.5:
+        # the chain kernels hold 152 KiB of a CU's LDS and the weight-gradient GEMM 128 KiB, so the two never share a CU and the
+        # "quarter-busy" coarse chains cannot be filled in.  Off by default; kept because it is tested (bits 4 / 8 of accumulate).
+        split = deferred and ctx.has_fine and model.mlp_fine is not None and os.environ.get("PNYOLO_SPLIT_FLUSH", "0") == "1"
+        fstream = None
+        if split:
+            for sb in range(SB):
+                run(sb, 4)     # (bit 4: the fine pass only; bit 8: the coarse pass only -- include/pnyolo.h pny_render_backward)
+            main = torch.cuda.current_stream(dev)
+            fstream = getattr(model, "_flush_stream", None)
+            if fstream is None or fstream.device != dev:
+                fstream = model._flush_stream = torch.cuda.Stream(dev)
+            fstream.wait_stream(main)
+            for st_ in streams:
+                if st_ is not None:
+                    fstream.wait_stream(st_)
+            with torch.cuda.stream(fstream):
+                check(L.pny_model_flush_weight_grads(model._h_model, 1 | 32, stream_of(dev)))
+            for sb in range(SB):
+                run(sb, 8)
+        else:
+            for sb in range(SB):
+                run(sb, 0)
         if deferred:
             model.join_streams(streams)
         # d loss / d latent is complete here, BEFORE the weight-gradient flush is enqueued: the encoder's backward (the trunk's
@@ -293,7 +321,9 @@ class _RenderFunction(torch.autograd.Function):
             model._lat_grad_event = torch.cuda.Event()
             model._lat_grad_event.record(torch.cuda.current_stream(dev))
         if deferred:
-            check(L.pny_model_flush_weight_grads(model._h_model, 1, stream_of(dev)))
+            check(L.pny_model_flush_weight_grads(model._h_model, 1 | (16 if split else 0), stream_of(dev)))
+            if fstream is not None:
+                torch.cuda.current_stream(dev).wait_stream(fstream)
             check(L.pny_model_defer_weight_grads(model._h_model, 0, 0, 0, 0))
         return (None, None, None, None, None) + tuple(grads) + extra
 

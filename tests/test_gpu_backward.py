@@ -453,12 +453,14 @@ def test_device_refresh_equals_full_reupload():
     assert not torch.equal(stale, fresh)
 
 
-@pytest.mark.parametrize("streams", ["1", "0"])
+@pytest.mark.parametrize("streams", ["1", "0", "split"])
 def test_render_backward_super_batch(streams, monkeypatch):
     """SB = 3 scenes x B rays (the reference's training batch shape): the scenes' backward calls append to one
     model-level stash (deferred weight gradients, side streams unless PNYOLO_SCENE_STREAMS=0) and one weight-gradient
     GEMM per MLP sums over all of them; against the sum of the oracle's per-scene gradients."""
-    monkeypatch.setenv("PNYOLO_SCENE_STREAMS", streams)
+    # "split": every scene's fine pass, mlp_fine's flush on its own stream, then the coarse passes (pny_render_backward bits 4 / 8)
+    monkeypatch.setenv("PNYOLO_SCENE_STREAMS", "1" if streams == "split" else streams)
+    monkeypatch.setenv("PNYOLO_SPLIT_FLUSH", "1" if streams == "split" else "0")
     SB, ns, H, W, kc, kf, kfd, n = 3, 2, 32, 32, 16, 8, 4, 24
     c = pconf.default_mv()
     net = make_model(c["model"], stop_encoder_grad=True)
