@@ -107,6 +107,9 @@ __device__ __forceinline__ void h2gemm(f32x16 (&acc)[h2::NT][h2::MT], H2Ring& r,
         // `side` (loads whose results are needed after this GEMM: the first chunk of the next block's gather) is issued
         // from INSIDE the loop: placed in front of it the compiler sinks the loads behind the loop, to their first use
         if (j == WD) side();
+#ifdef PNY_H2_EXP_LOCKSTEP   // experiment: a workgroup barrier every PNY_H2_EXP_LOCKSTEP steps keeps the two waves of a SIMD level
+        if (j > 0 && (j % PNY_H2_EXP_LOCKSTEP) == 0) __builtin_amdgcn_s_barrier();
+#endif
 #pragma unroll
         for (int d = 0; d < WD; ++d) {
             const int jd = j + d;
