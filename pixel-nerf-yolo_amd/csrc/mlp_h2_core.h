@@ -45,9 +45,13 @@ __device__ __forceinline__ H2Seg h2seg(const WStream& ws, const float* packed, i
     s.jn = jn;
     return s;
 }
+// cache policy of the weight-fragment loads (gfx940+ aux bits: 1 = sc0, 2 = nt, 16 = sc1)
+#ifndef PNY_H2_WAUX
+#define PNY_H2_WAUX 0
+#endif
 // fragment (step j, local n-tile nt, plane p): this lane's 16 bytes = 8 halves W[32 nt_g + (l & 31)][16 j + 8 (l >> 5) + 0..7]
 __device__ __forceinline__ h8 h2load(const WStream& ws, unsigned seg_off, int nt, int p, int j) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.lane_off, seg_off + (unsigned)(((j * 16 + nt) * 2 + p) * 64) * 16u, 0);
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.lane_off, seg_off + (unsigned)(((j * 16 + nt) * 2 + p) * 64) * 16u, PNY_H2_WAUX);
     return __builtin_bit_cast(h8, v);
 }
 struct H2Ring {
