@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PNY_ABI_VERSION 10
+#define PNY_ABI_VERSION 11
 
 typedef enum pny_status {
     PNY_OK = 0,
@@ -106,6 +106,16 @@ void pny_scene_destroy(pny_scene* s);
  * were launched with). */
 int pny_scene_set_cameras(pny_scene* s, const float* poses_host, int ns, const float* focal_host, int nf,
                           const float* c_host, int nc, int width, int height);
+/* Super-batch in ONE scene (ABI 11).  The reference flattens a super-batch everywhere: NeRFRenderer.forward takes rays
+ * (SB, B, 8) and composites (SB * B) rays in one pass (src/render/nerf.py:283-288), PixelNeRFNet.forward conditions object o's
+ * points on ITS views out of the (SB * NS) encoded ones (src/model/models.py:160-246, util.repeat_interleave).  With
+ * n_objs > 1 the scene's ns views (cameras and latent, object-major) are n_objs objects' view lists of ns / n_objs views each,
+ * and every later render / query / backward call splits its rays (points) into n_objs equal consecutive shares, share o seeing
+ * views [o * ns / n_objs, (o + 1) * ns / n_objs): one MLP launch per pass covers all objects' tiles.  Every share's sample
+ * count (rays x samples per ray, in both passes) must be a multiple of 64 -- PNY_ERR_ARG otherwise, and the caller falls
+ * back to one scene per object; the backward of a grouped scene needs the deferred stash (pny_model_defer_weight_grads).
+ * ns <= 16 views in total.  n_objs = 1 restores the default. */
+int pny_scene_set_groups(pny_scene* s, int n_objs);
 /* Encoder bypass: installs a latent (ns, L, Hl, Wl) NCHW as SpatialEncoder.forward would leave
  * it in self.latent (src/model/encoder.py:169-172); repacked to NHWC on device. */
 int pny_scene_set_latent(pny_scene* s, const float* latent_dev, int ns, int channels, int hl, int wl,

@@ -601,6 +601,13 @@ int pny_scene_set_cameras(pny_scene* s, const float* poses, int ns, const float*
     return PNY_OK;
 }
 
+int pny_scene_set_groups(pny_scene* s, int n_objs) {
+    if (!s) return fail(PNY_ERR_ARG, "pny_scene_set_groups: null scene");
+    if (n_objs < 1 || n_objs > MAX_VIEWS) return fail(PNY_ERR_ARG, "pny_scene_set_groups: n_objs out of range [1,16]");
+    s->n_objs = n_objs;   // (the view count is checked against it when a call needs both: check_ready)
+    return PNY_OK;
+}
+
 int pny_scene_set_latent(pny_scene* s, const float* latent_dev, int ns, int channels, int hl, int wl, pny_stream stream) {
     if (!s || !latent_dev) return fail(PNY_ERR_ARG, "pny_scene_set_latent: null argument");
     if (channels != s->m->desc.d_latent) return fail(PNY_ERR_ARG, "pny_scene_set_latent: channel count != model d_latent");
@@ -814,7 +821,9 @@ int check_ready(pny_scene* s, const char* who) {
     if (!s->have_latent) return fail(PNY_ERR_STATE, std::string(who) + ": scene has no latent (pny_scene_encode / pny_scene_set_latent)");
     if (!s->have_cams) return fail(PNY_ERR_STATE, std::string(who) + ": scene has no cameras (pny_scene_set_cameras)");
     if (s->cam_ns != s->ns) return fail(PNY_ERR_STATE, std::string(who) + ": camera count != latent view count");
-    if (s->ns > 1 && s->m->desc.combine_layer >= s->m->desc.n_blocks)
+    if (s->n_objs > 1 && s->ns % s->n_objs)
+        return fail(PNY_ERR_STATE, std::string(who) + ": grouped scene: the view count is not a multiple of the object count");
+    if (obj_views(s) > 1 && s->m->desc.combine_layer >= s->m->desc.n_blocks)
         return fail(PNY_ERR_ARG, std::string(who) + ": multi-view scene needs combine_layer < n_blocks");
     return 0;
 }
@@ -904,7 +913,13 @@ int fill_mlp_args(pny_scene* s, int mode, const float* xyz, const float* dirs, c
     a.n_points = n_points;
     a.K = K;
     a.mode = mode;
-    a.NS = s->ns;
+    a.NS = obj_views(s);
+    a.obj_pts = 0;
+    if (s->n_objs > 1) {   // grouped scene: equal consecutive shares, whole tiles per object (pny_scene_set_groups)
+        if (n_points % s->n_objs || (n_points / s->n_objs) % 64)
+            return fail(PNY_ERR_ARG, "grouped scene: every object's share of the samples must be the same multiple of 64");
+        a.obj_pts = n_points / s->n_objs;
+    }
     a.L = s->L;
     a.Hl = s->hl;
     a.Wl = s->wl;
@@ -949,8 +964,8 @@ static int run_mlp(pny_scene* s, int mode, const float* xyz, const float* dirs, 
         const int which = fine_w ? 1 : 0;
         pny_scene::StashedPass& sp = s->stashed[stash_pass];
         sp.valid = false;
-        if (m->defer && s->ns == m->defer_ns && m->defer_used[which] + a.n_tiles <= m->defer_cap[which]) {
-            a.lay = stash_layout(d, s->ns, s->L);
+        if (m->defer && obj_views(s) == m->defer_ns && m->defer_used[which] + a.n_tiles <= m->defer_cap[which]) {
+            a.lay = stash_layout(d, obj_views(s), s->L);
             a.stash_x = m->dx_stash[which].f() + m->defer_used[which] * a.lay.x_tile;
             sp.valid = true;
             sp.epoch = m->defer_epoch;
@@ -986,8 +1001,8 @@ static int run_mlp(pny_scene* s, int mode, const float* xyz, const float* dirs, 
                 PNY_HIP(hipEventRecord(s->ev[s->ev_used + 1], st));
                 s->ev_used += 2;
             }
-            s->last_flops += mlp_flops_per_point(d, s->ns, !use_h2) * (double)n_points;
-            s->last_flops_ref += mlp_flops_per_point(d, s->ns, true) * (double)n_points;
+            s->last_flops += mlp_flops_per_point(d, obj_views(s), !use_h2) * (double)n_points;
+            s->last_flops_ref += mlp_flops_per_point(d, obj_views(s), true) * (double)n_points;
             s->last_projected = use_h2;
             s->last_f16x2 = use_h2;
             s->last_launches += 1;
@@ -1055,8 +1070,8 @@ static int run_mlp(pny_scene* s, int mode, const float* xyz, const float* dirs, 
         s->ev_used += 2;
     }
     s->last_f16x2 = use_h2;
-    s->last_flops += mlp_flops_per_point(d, s->ns, a.zp == nullptr) * (double)n_points;
-    s->last_flops_ref += mlp_flops_per_point(d, s->ns, true) * (double)n_points;
+    s->last_flops += mlp_flops_per_point(d, obj_views(s), a.zp == nullptr) * (double)n_points;
+    s->last_flops_ref += mlp_flops_per_point(d, obj_views(s), true) * (double)n_points;
     s->last_projected = a.zp != nullptr;
     s->last_launches += 1;
     return 0;

@@ -170,6 +170,7 @@ struct pny_scene {
     int width = 0, height = 0;
     bool have_cams = false, have_latent = false;
     int cam_ns = 0;
+    int n_objs = 1;       // pny_scene_set_groups: the views are n_objs objects' view lists, ns / n_objs each (MlpArgs::obj_pts)
     Cam cams[MAX_VIEWS];  // host copy; handed to every MLP launch as kernel arguments
     DevBuf latent, work, scratch, enc_work;
     // projected latent of the coarse [0] / fine [1] MLP (see ensure_projection)
@@ -217,6 +218,7 @@ namespace pny {
 int enter_stream(pny_scene* s, hipStream_t st);
 int check_ready(pny_scene* s, const char* who);
 int view_blocks(const pny_model_desc& d);
+inline int obj_views(const pny_scene* s) { return s->ns / (s->n_objs > 0 ? s->n_objs : 1); }   // views per object
 StashLayout stash_layout(const pny_model_desc& d, int ns, int L);
 // projected latent maps of the coarse (0) / fine (1) MLP, computed if stale; force = regardless of the scene's mode
 int ensure_projection(pny_scene* s, int which, long long n_points, hipStream_t st, const float** zp, bool force = false);

@@ -31,6 +31,7 @@ __global__ __launch_bounds__(64 * LG_NW) void latent_grad_kernel(const MlpArgs a
     const long long tv = blockIdx.x / nblocks;
     const int v = (int)(tv % a.NS);
     const long long tile = tv / a.NS;
+    const int vabs = tile_view_base(a, tile * 64) + v;   // index into the scene's view list (grouped scenes)
     const int K = nvb * HID, J = K / 8;
     if (tid < 64) {
         long long s = tile * 64 + tid;
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(64 * LG_NW) void latent_grad_kernel(const MlpArgs a
         float wgt[4];
         const bool live = s < a.n_points;
         if (!live) s = a.n_points - 1;
-        sample_taps(a, v, s, offs, wgt);
+        sample_taps(a, vabs, s, offs, wgt);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             tap_off[tid][k] = offs[k];
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(64 * LG_NW) void latent_grad_kernel(const MlpArgs a
     // scatter.  In accumulator layout a lane holds 4 channels of ONE sample, i.e. a wave instruction would touch 32 different
     // pixels' lines; the wave's 64 channels x 32 samples are turned through LDS instead, so that one atomic instruction
     // adds 64 CONSECUTIVE channels of one sample's tap (two 128-byte lines): 16x fewer line operations at the L2
-    float* gv = grad + (size_t)v * a.Hl * a.Wl * a.L + 32 * nt0 + lane;
+    float* gv = grad + (size_t)vabs * a.Hl * a.Wl * a.L + 32 * nt0 + lane;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         __syncthreads();   // (the staging buffers / the previous half's rows are no longer read)
@@ -157,6 +158,7 @@ __global__ __launch_bounds__(64 * LG_NW) void latent_grad_h2_kernel(const MlpArg
     const long long tv = blockIdx.x / nblocks;
     const int v = (int)(tv % a.NS);
     const long long tile = tv / a.NS;
+    const int vabs = tile_view_base(a, tile * 64) + v;   // index into the scene's view list (grouped scenes)
     const int K = nvb * HID, J = K / 8;
     float scale = 1.0f, inv_scale = 1.0f;
     {
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(64 * LG_NW) void latent_grad_h2_kernel(const MlpArg
         float wgt[4];
         const bool live = s < a.n_points;
         if (!live) s = a.n_points - 1;
-        sample_taps(a, v, s, offs, wgt);
+        sample_taps(a, vabs, s, offs, wgt);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             tap_off[tid][k] = offs[k];
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(64 * LG_NW) void latent_grad_h2_kernel(const MlpArg
             __syncthreads();
         }
     }
-    float* gv = grad + (size_t)v * a.Hl * a.Wl * a.L + 32 * nt0 + lane;
+    float* gv = grad + (size_t)vabs * a.Hl * a.Wl * a.L + 32 * nt0 + lane;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         __syncthreads();

@@ -96,6 +96,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void pny_mlp_kernel(const MlpAr
     for (long long tile = t_first; tile < t_last; tile += t_step) {
         f32x16 h[NT][MT];
         float* const x_rec = STASH ? a.stash_x + tile * a.lay.x_tile : nullptr;
+        const int vb = tile_view_base(a, tile * C::TM);   // grouped scene: the tile's object sees views vb .. vb + NS - 1
         for (int v = 0; v < a.NS; ++v) {
             float* const x_view = STASH ? x_rec + (size_t)v * a.lay.x_view : nullptr;
             auto act_slot = [&](int i) { return reinterpret_cast<float4*>(x_view + a.lay.x_act + (size_t)i * STASH_SLOT); };
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void pny_mlp_kernel(const MlpAr
                     constexpr int WIN = (GCH / 4) * TMc;
                     GatherTaps<C, 2> g;
                     ST_BEGIN();
-                    gather_setup<C>(g, a.zp + (size_t)v * a.Hl * a.Wl * a.zp_stride + blk * HID, tap_tab, wave, lane);
+                    gather_setup<C>(g, a.zp + (size_t)(vb + v) * a.Hl * a.Wl * a.zp_stride + blk * HID, tap_tab, wave, lane);
                     gather_issue<C, 0>(g, 0, wave);
                     gather_issue<C, 1>(g, GCH, wave);
                     __builtin_amdgcn_sched_barrier(0);
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void pny_mlp_kernel(const MlpAr
                     GatherTaps<C> g;
                     {
                         ST_BEGIN();
-                        gather_setup<C>(g, a.latent + (size_t)v * a.Hl * a.Wl * a.L, tap_tab, wave, lane);
+                        gather_setup<C>(g, a.latent + (size_t)(vb + v) * a.Hl * a.Wl * a.L, tap_tab, wave, lane);
                         gather_issue<C>(g, 0, wave);
                         __builtin_amdgcn_sched_barrier(0);
                         __syncthreads();  // every wave is done reading the buffer (previous GEMM)

@@ -754,8 +754,10 @@ __global__ __launch_bounds__(256) void mlp_dz_kernel(const DzArgs a) {
     const float* dy_rec = a.dy_stash + tile * a.lay.dy_tile;
     const int ncode = 3 + 6 * a.num_freqs;
     float acc = 0.f;
+    // grouped scene (MlpArgs::obj_pts): the sample's object sees views vb .. vb + NS - 1 of the view list (wave-uniform)
+    const int vb = a.obj_pts ? __builtin_amdgcn_readfirstlane((int)((long long)idx / a.obj_pts) * a.NS) : 0;
     for (int v = 0; v < a.NS; ++v) {
-        const Cam cam = a.cams[v];
+        const Cam cam = a.cams[vb + v];
         float xr[3], xc[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -815,7 +817,7 @@ __global__ __launch_bounds__(256) void mlp_dz_kernel(const DzArgs a) {
             const bool cull = (a.yolo && !(xc[2] < 0.0f)) || !(ix == ix) || !(iy == iy);
             float six = 0.f, siy = 0.f;
             if (!cull) {
-                const float* zv = a.zp + (size_t)v * a.Hl * a.Wl * a.zp_stride;
+                const float* zv = a.zp + (size_t)(vb + v) * a.Hl * a.Wl * a.zp_stride;
                 for (int b = 0; b < a.nvb; ++b) {
                     const float* dhb = dy_rec + (size_t)v * a.lay.dy_view + (size_t)(2 * b + 1) * STASH_SLOT;
                     const float4 h0 = *reinterpret_cast<const float4*>(dhb + ((size_t)(2 * lane) * 64 + m) * 4);

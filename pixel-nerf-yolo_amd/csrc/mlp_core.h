@@ -492,6 +492,14 @@ __device__ __forceinline__ void load_point(const MlpArgs& a, long long s, float 
     }
 }
 
+// First view of the object a tile's samples belong to (MlpArgs::obj_pts; 0 for an ungrouped scene).  Uniform per tile.
+__device__ __forceinline__ int tile_view_base(const MlpArgs& a, long long first_sample) {
+    if (a.obj_pts == 0) return 0;
+    if (first_sample >= a.n_points) first_sample = a.n_points - 1;
+    const long long obj = a.idx32 ? (long long)((unsigned)first_sample / (unsigned)a.obj_pts) : first_sample / a.obj_pts;
+    return (int)obj * a.NS;
+}
+
 // Positional-code entry e of the 64-row (42 valid) input column (reference code.py:30-42 layout:
 // [x(3), then per frequency sin(f x)(3), sin(f x + pi/2)(3)], then view dirs (models.py:207)).
 __device__ __forceinline__ float input_entry(int e, const float (&xr)[3], const float (&vd)[3], float freq_factor,
@@ -520,7 +528,7 @@ __device__ __forceinline__ void prologue(const MlpArgs& a, int v, long long tile
     if (s >= a.n_points) s = a.n_points - 1;
     float p[3], d[3];
     load_point(a, s, p, d);
-    const Cam cam = a.cams[v];
+    const Cam cam = a.cams[tile_view_base(a, tile * TMc) + v];
     float xr[3], xc[3], vd[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -580,6 +588,7 @@ __device__ __forceinline__ void prologue(const MlpArgs& a, int v, long long tile
 // The four bilinear taps of sample s in source view v: element offsets (pixel index x tap_stride) and weights, exactly as
 // the prologue above computes them (projection models.py:219-230; grid_sample coordinates encoder.py:97-98,
 // align_corners=True, zeros padding; YOLO-mode culling).  Used by kernels outside the forward chain (latent_grad.hip).
+// v: index into the scene's view list (a grouped scene: tile_view_base + the object's view).
 __device__ __forceinline__ void sample_taps(const MlpArgs& a, int v, long long s, int (&offs)[4], float (&wgt)[4]) {
     float p[3], d[3];
     load_point(a, s, p, d);

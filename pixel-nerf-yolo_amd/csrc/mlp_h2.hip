@@ -246,7 +246,7 @@ __device__ __forceinline__ void h2prologue(const MlpArgs& a, int v, long long ti
     if (s >= a.n_points) s = a.n_points - 1;
     float p[3], d[3];
     load_point(a, s, p, d);
-    const Cam cam = a.cams[v];
+    const Cam cam = a.cams[tile_view_base(a, tile * TM) + v];
     float xr[3], xc[3], vd[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -433,6 +433,9 @@ __global__ __launch_bounds__(h2::THREADS, 2) void PNY_H2_KERNEL(const MlpArgs a)
             }
         };
         for (int v = 0; v < a.NS; ++v) {
+            // grouped scene: the tile's object sees views vb .. vb + NS - 1 (recomputed per view: a value kept across the
+            // GEMM loops costs SGPR spills)
+            const int vb = tile_view_base(a, tile * TM);
             const H2Seg after_view = v + 1 < a.NS ? s_in : (nvb < nb ? fc0seg(nvb) : s_in);
             const unsigned x_view = STASH ? (unsigned)v * (unsigned)a.lay.x_view * 4u : 0u;
             auto act_slot = [&](int i) { return x_view + ((unsigned)a.lay.x_act + (unsigned)i * (unsigned)STASH_SLOT) * 4u; };
@@ -446,7 +449,7 @@ __global__ __launch_bounds__(h2::THREADS, 2) void PNY_H2_KERNEL(const MlpArgs a)
                 // gradient: gathered from the latent itself, 128 channels at a time, two chunks in flight, written straight
                 // to the stash (a lane holds 4 channels of one sample = one float4 of the [channel/4][sample] tile)
                 const unsigned xz = x_view + (unsigned)a.lay.x_z * 4u;
-                gather_setup<C>(g, a.latent + (size_t)v * a.Hl * a.Wl * a.L, tap_raw, wave, lane);
+                gather_setup<C>(g, a.latent + (size_t)(vb + v) * a.Hl * a.Wl * a.L, tap_raw, wave, lane);
                 const int nch = a.L / GCH;
                 const unsigned zlane = (unsigned)(((lane >> 3) * TM + (wave % 8) * 8 + (lane & 7)) * 16);
                 auto put = [&](const float4(&x)[4][4], int c) {
@@ -470,7 +473,7 @@ __global__ __launch_bounds__(h2::THREADS, 2) void PNY_H2_KERNEL(const MlpArgs a)
                     if (c + 1 < nch) put(g.x[1], c + 1);
                 }
             }
-            gather_setup<C>(g, a.zp + (size_t)v * a.Hl * a.Wl * a.zp_stride, tap_tab, wave, lane);
+            gather_setup<C>(g, a.zp + (size_t)(vb + v) * a.Hl * a.Wl * a.zp_stride, tap_tab, wave, lane);
             gather_issue<C, 0>(g, 0, wave);   // block 0, chunk 0
             HS_LAP(HS_PROLOGUE);
             h2gemm(h, ring, ws, s_in, fc0seg(0), planes, lane);

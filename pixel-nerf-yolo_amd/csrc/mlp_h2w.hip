@@ -315,7 +315,7 @@ __device__ __forceinline__ void hwprologue(const MlpArgs& a, int v, long long ti
     if (s >= a.n_points) s = a.n_points - 1;
     float p[3], d[3];
     load_point(a, s, p, d);
-    const Cam cam = a.cams[v];
+    const Cam cam = a.cams[tile_view_base(a, tile * TM) + v];
     float xr[3], xc[3], vd[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(hw::THREADS) __attribute__((amdgpu_waves_per_eu(hw:
             hwprologue(a, v, tile, planes, tap_tab, tid);
             hwzero(h);
             __syncthreads();
-            zp_view = a.zp + (size_t)v * a.Hl * a.Wl * a.zp_stride;
+            zp_view = a.zp + (size_t)(tile_view_base(a, tile * hw::TM) + v) * a.Hl * a.Wl * a.zp_stride;
             if (PREFETCH) {   // block 0's first pieces travel underneath the lin_in GEMM
                 HwTaps gp;
                 hwgather_setup(gp, zp_view, tap_tab, wave, lane);

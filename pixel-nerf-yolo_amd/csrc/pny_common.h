@@ -82,6 +82,11 @@ struct MlpArgs {
     float freq_factor;
     float sx, sy;     // latent_scaling / image_size (reference encoder.py:97)
     int n_tiles;
+    // Grouped scene (pny_scene_set_groups: the reference's super-batch, NeRFRenderer.forward flattening (SB, B, 8) rays and
+    // PixelNeRFNet.forward conditioning object o on its own NS views, nerf.py:283-288, models.py:160-218): the launch's samples
+    // belong to n_objs objects in equal consecutive shares of obj_pts samples, object o sees cams / latent views
+    // [o NS, (o + 1) NS) of the scene's view list.  obj_pts is a multiple of 64, so a tile never straddles objects.  0: one object.
+    long long obj_pts;
     // training: activation stash written by the STASH instantiation (launch_mlp_stash); null otherwise
     float* stash_x;
     StashLayout lay;
@@ -172,6 +177,7 @@ struct DzArgs {
     const float* zp;      // projected maps of this MLP (api.hip ensure_projection) or null
     int zp_stride;
     int NS, Hl, Wl, nvb, npost, yolo, num_freqs;
+    long long obj_pts;    // grouped scene (MlpArgs::obj_pts): samples per object, 0 = one object
     float freq_factor, sx, sy;
     float* dz;            // (n_points of the pass) accumulated
     Cam cams[MAX_VIEWS];

@@ -283,10 +283,12 @@ int mlp_backward(pny_scene* s, int mode, const float* xyz, const float* dirs, co
     const bool have_x = !immediate && stashed && stashed->valid && m->defer && stashed->epoch == m->defer_epoch &&
                         stashed->n_points == n_points && fwd_out;
     const bool defer = m->defer && !immediate;
+    if (s->n_objs > 1 && !have_x && !defer)   // (the chunked recompute path would split an object's share)
+        return fail(PNY_ERR_STATE, "grouped scene: the backward needs the deferred stash (pny_model_defer_weight_grads)");
     const pny_model_desc& d = m->desc;
     const bool fine_w = !(coarse || !d.has_fine || !m->use_fine);
     const std::string pre = fine_w ? "mlp_fine." : "mlp_coarse.";
-    TrainPlan plan = build_plan(m, s->ns, s->L, pre);
+    TrainPlan plan = build_plan(m, obj_views(s), s->L, pre);
     const size_t tile_bytes = (size_t)(plan.lay.x_tile + plan.lay.dy_tile) * sizeof(float);
     long long max_tiles = (long long)(stash_budget_bytes() / tile_bytes);
     if (max_tiles < 1) return fail(PNY_ERR_ARG, "stash budget smaller than one tile");
@@ -308,7 +310,7 @@ int mlp_backward(pny_scene* s, int mode, const float* xyz, const float* dirs, co
         dy_base = m->ddy_stash[stashed->which].f() + stashed->tile0 * plan.lay.dy_tile;
     } else if (defer) {
         const long long tiles = (n_points + 63) / 64;
-        if (s->ns != m->defer_ns) return fail(PNY_ERR_STATE, "deferred weight gradients: scene view count differs from the reservation");
+        if (obj_views(s) != m->defer_ns) return fail(PNY_ERR_STATE, "deferred weight gradients: scene view count differs from the reservation");
         if (m->defer_used[which] + tiles > m->defer_cap[which])
             return fail(PNY_ERR_STATE, "deferred weight gradients: more tiles than pny_model_defer_weight_grads reserved");
         chunk_pts = n_points;   // one chunk: the reservation was made against the budget
@@ -348,8 +350,8 @@ int mlp_backward(pny_scene* s, int mode, const float* xyz, const float* dirs, co
         const int nvb_ = view_blocks(d), npost_ = d.n_blocks - nvb_, d_in_ = 3 + 6 * d.num_freqs + 3;
         const double per_view_f = (double)d_in_ * HID + (double)nvb_ * s->L * HID + 2.0 * nvb_ * HID * HID;
         const double post_f = 2.0 * npost_ * HID * HID + (double)HID * d.d_out;
-        const double fwd = 2.0 * (s->ns * per_view_f + post_f);
-        const double chain = 2.0 * (s->ns * 2.0 * nvb_ * HID * HID + 2.0 * npost_ * HID * HID + (double)HID * d.d_out);
+        const double fwd = 2.0 * (obj_views(s) * per_view_f + post_f);
+        const double chain = 2.0 * (obj_views(s) * 2.0 * nvb_ * HID * HID + 2.0 * npost_ * HID * HID + (double)HID * d.d_out);
         if (!have_x) s->bwd_flops[0] += fwd * (double)n_points;   // the forward already stashed: nothing is recomputed
         s->bwd_flops[1] += chain * (double)n_points;
         s->bwd_flops[2] += fwd * (double)n_points;   // every forward GEMM has one weight-gradient GEMM of the same size
@@ -395,7 +397,7 @@ int mlp_backward(pny_scene* s, int mode, const float* xyz, const float* dirs, co
         b.d_out_grad = d_out + p0 * d.d_out;
         b.n_points = np;
         b.n_tiles = n_tiles;
-        b.NS = s->ns;
+        b.NS = obj_views(s);
         b.n_blocks = d.n_blocks;
         b.combine_layer = d.combine_layer;
         b.d_out = d.d_out;
@@ -431,7 +433,8 @@ int mlp_backward(pny_scene* s, int mode, const float* xyz, const float* dirs, co
             dz.d_in = 3 + 6 * d.num_freqs + 3;
             dz.zp = zp_maps;
             dz.zp_stride = view_blocks(d) * HID;
-            dz.NS = s->ns;
+            dz.NS = obj_views(s);
+            dz.obj_pts = a.obj_pts;
             dz.Hl = s->hl;
             dz.Wl = s->wl;
             dz.nvb = view_blocks(d);
@@ -628,7 +631,7 @@ int pny_render_backward(pny_scene* s, const float* rays_dev, int64_t n, const pn
     const bool depth_path = any_f && kfd > 0 && sv->depth_coarse;
     {   // a pass that was stashed by the forward but receives no gradient must not leave stale dY tiles for the flush
         pny_model* m = s->m;
-        const long long dy_tile = stash_layout(m->desc, s->ns, s->L).dy_tile;
+        const long long dy_tile = stash_layout(m->desc, obj_views(s), s->L).dy_tile;
         auto zero_pass = [&](const pny_scene::StashedPass& sp) -> int {
             if (sp.valid && m->defer && !immediate && sp.epoch == m->defer_epoch)
                 PNY_HIP(hipMemsetAsync(m->ddy_stash[sp.which].f() + sp.tile0 * dy_tile, 0, (size_t)sp.tiles * dy_tile * sizeof(float), st));

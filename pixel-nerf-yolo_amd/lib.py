@@ -64,6 +64,7 @@ SIGNATURES = {
     "pny_model_refresh": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pny_scene_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p]),
     "pny_scene_destroy": (None, [C.c_void_p]),
+    "pny_scene_set_groups": (C.c_int, [C.c_void_p, C.c_int]),
     "pny_scene_set_cameras": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                         C.c_int, C.c_int]),
     "pny_scene_set_latent": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -121,7 +122,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 10
+ABI_VERSION = 11
 PROJECTION = {"off": 0, "on": 1, "auto": 2}
 PRECISION = {"f32": 0, "f16x2": 1, "auto": 2}
 

@@ -261,6 +261,13 @@ class PixelNeRFNet(nn.Module):
         self._h_device = None
         self._h_has_fine = False
         self._h_scenes = []
+        # Super-batch in ONE scene (include/pnyolo.h pny_scene_set_groups): the training render of SB > 1 objects runs on this
+        # handle -- one MLP launch per pass over every object's tiles.  _group = dict(SB, NS) while it holds the last encode();
+        # the per-object handles are then filled on first use (_scenes_pending).
+        self._h_group = None
+        self._group = None
+        self._scenes_pending = None
+        self._last_call_group = False
         self._synced_key = None
         self._dev_bound = False
         self._timing = False
@@ -286,6 +293,9 @@ class PixelNeRFNet(nn.Module):
         for s in self._h_scenes:
             L.pny_scene_destroy(s)
         self._h_scenes = []
+        if getattr(self, "_h_group", None) is not None:
+            L.pny_scene_destroy(self._h_group)
+        self._h_group, self._group, self._scenes_pending = None, None, None
         if self._h_model is not None:
             L.pny_model_destroy(self._h_model)
             self._h_model = None
@@ -372,23 +382,71 @@ class PixelNeRFNet(nn.Module):
         # `net.mlp_fine = None` (reference eval.py:140): fine pass falls back to the coarse MLP
         check(L.pny_model_use_fine(self._h_model, int(self.mlp_fine is not None)))
 
-    def _scene(self, i):
+    def _new_scene(self):
         L = _lib.load()
+        s = C.c_void_p()
+        check(L.pny_scene_create(C.byref(s), self._h_model))
+        check(L.pny_scene_enable_timing(s, int(self._timing)))
+        if self._projection is not None:
+            check(L.pny_scene_set_projection(s, _lib.PROJECTION[self._projection]))
+        if self._precision is not None:
+            check(L.pny_scene_set_precision(s, _lib.PRECISION[self._precision]))
+        return s
+
+    def _scene(self, i):
+        if self._scenes_pending is not None:
+            self._materialise_scenes()
         while len(self._h_scenes) <= i:
-            s = C.c_void_p()
-            check(L.pny_scene_create(C.byref(s), self._h_model))
-            check(L.pny_scene_enable_timing(s, int(self._timing)))
-            if self._projection is not None:
-                check(L.pny_scene_set_projection(s, _lib.PROJECTION[self._projection]))
-            if self._precision is not None:
-                check(L.pny_scene_set_precision(s, _lib.PRECISION[self._precision]))
-            self._h_scenes.append(s)
+            self._h_scenes.append(self._new_scene())
         return self._h_scenes[i]
+
+    def _group_scene(self):
+        """The handle that holds a whole super-batch (pny_scene_set_groups); None unless the last encode() filled it."""
+        return self._h_group if self._group is not None else None
+
+    def _handles(self):
+        return list(self._h_scenes) + ([self._h_group] if self._h_group is not None else [])
+
+    def _stat_handles(self):
+        if self._last_call_group and self._group is not None:
+            return [self._h_group]
+        return self._h_scenes[: max(self.num_objs, 1)]
+
+    @staticmethod
+    def _cam_rows(t, sb, SB, NS):
+        """focal / c rows of object sb: batch 1 broadcasts, batch SB is per object, batch SB*NS per view."""
+        if t.shape[0] == 1:
+            return t[:1]
+        if t.shape[0] == SB * NS:
+            return t[sb * NS:(sb + 1) * NS]
+        if t.shape[0] == SB:
+            return t[sb:sb + 1]
+        raise ValueError("focal / c batch must be 1, SB or SB*NS")
+
+    def _materialise_scenes(self):
+        """Per-object scene handles from the grouped one (cameras from the encode() arguments, latent copied out of it): only
+        when something other than the training render asks for them after a grouped encode()."""
+        pend, self._scenes_pending = self._scenes_pending, None
+        L = _lib.load()
+        dev = self._device()
+        SB, NS = self._group["SB"], self._group["NS"]
+        dims = [C.c_int() for _ in range(4)]
+        check(L.pny_scene_latent_shape(self._h_group, *[C.byref(d) for d in dims]))
+        lat = torch.empty([d.value for d in dims], device=dev, dtype=torch.float32)
+        check(L.pny_scene_get_latent(self._h_group, ptr(lat), stream_of(dev)))
+        for sb in range(SB):
+            s = self._scene(sb)
+            f_s = self._cam_rows(pend["focal"], sb, SB, NS).contiguous()
+            c_s = self._cam_rows(pend["c"], sb, SB, NS).contiguous()
+            p_s = pend["poses"][sb * NS:(sb + 1) * NS].contiguous()
+            check(L.pny_scene_set_cameras(s, ptr(p_s), NS, ptr(f_s), f_s.shape[0], ptr(c_s), c_s.shape[0], pend["W"], pend["H"]))
+            part = lat[sb * NS:(sb + 1) * NS]
+            check(L.pny_scene_set_latent(s, ptr(part), NS, part.shape[1], part.shape[2], part.shape[3], stream_of(dev)))
 
     def enable_kernel_timing(self, on=True):
         """HIP-event timing of the MLP launches (bench.py's roofline leg)."""
         self._timing = bool(on)
-        for s in self._h_scenes:
+        for s in self._handles():
             check(_lib.load().pny_scene_enable_timing(s, int(on)))
 
     def set_latent_projection(self, mode):
@@ -398,7 +456,7 @@ class PixelNeRFNet(nn.Module):
         if mode not in _lib.PROJECTION:
             raise ValueError("latent projection mode must be one of %s" % sorted(_lib.PROJECTION))
         self._projection = mode
-        for s in self._h_scenes:
+        for s in self._handles():
             check(_lib.load().pny_scene_set_projection(s, _lib.PROJECTION[mode]))
         return self
 
@@ -409,7 +467,7 @@ class PixelNeRFNet(nn.Module):
         if mode not in _lib.PRECISION:
             raise ValueError("matrix precision must be one of %s" % sorted(_lib.PRECISION))
         self._precision = mode
-        for s in self._h_scenes:
+        for s in self._handles():
             check(_lib.load().pny_scene_set_precision(s, _lib.PRECISION[mode]))
         return self
 
@@ -483,7 +541,7 @@ class PixelNeRFNet(nn.Module):
         fl = ref = ms = 0.0
         n = 0
         proj = False
-        for s in self._h_scenes[: max(self.num_objs, 1)]:
+        for s in self._stat_handles():
             a, r, b, c, p = C.c_double(), C.c_double(), C.c_double(), C.c_int(), C.c_int()
             check(L.pny_scene_last_mlp_stats(s, C.byref(a), C.byref(r), C.byref(b), C.byref(c), C.byref(p)))
             fl += a.value
@@ -500,7 +558,7 @@ class PixelNeRFNet(nn.Module):
         weight-gradient GEMMs (include/pnyolo.h pny_scene_last_backward_stats)."""
         L = _lib.load()
         fl, ms = [0.0] * 3, [0.0] * 3
-        for s in self._h_scenes[: max(self.num_objs, 1)]:
+        for s in self._stat_handles():
             a, b = (C.c_double * 3)(), (C.c_double * 3)()
             check(L.pny_scene_last_backward_stats(s, a, b))
             for i in range(3):
@@ -532,18 +590,24 @@ class PixelNeRFNet(nn.Module):
             return getattr(self, "_latent_src", None)
         return None
 
-    def begin_latent_grad(self, meta, n_scenes):
-        """Zeroed (SB * NS, Hl, Wl, L) accumulator bound slice by slice to the scenes (pny_scene_bind_latent_grad)."""
+    def begin_latent_grad(self, meta, n_scenes, group=False):
+        """Zeroed (SB * NS, Hl, Wl, L) accumulator bound slice by slice to the scenes (pny_scene_bind_latent_grad), or whole to
+        the grouped scene."""
         n_lat, l_ch, hl, wl = meta[0]
         buf = torch.zeros(n_lat, hl, wl, l_ch, device=self._device(), dtype=torch.float32)
+        if group:
+            check(_lib.load().pny_scene_bind_latent_grad(self._h_group, ptr(buf)))
+            return buf
         nsv = n_lat // n_scenes
         for sb in range(n_scenes):
             check(_lib.load().pny_scene_bind_latent_grad(self._scene(sb), ptr(buf[sb * nsv:(sb + 1) * nsv])))
         return buf
 
-    def end_latent_grad(self, buf, meta, n_scenes):
+    def end_latent_grad(self, buf, meta, n_scenes, group=False):
         """Unbind and return the gradient in the latent's own layout (SB * NS, L, Hl, Wl), device and dtype."""
-        for sb in range(n_scenes):
+        if group:
+            check(_lib.load().pny_scene_bind_latent_grad(self._h_group, None))
+        for sb in range(0 if group else n_scenes):
             check(_lib.load().pny_scene_bind_latent_grad(self._scene(sb), None))
         return buf.permute(0, 3, 1, 2).contiguous().to(meta[1], meta[2])   # packed NCHW, like the latent it belongs to
 
@@ -669,6 +733,28 @@ class PixelNeRFNet(nn.Module):
                 self._synced_key = None
                 self._sync()
             images = images.detach().to(dev, torch.float32).contiguous()
+        self._group, self._scenes_pending = None, None
+        if (SB > 1 and SB * NS <= 16 and os.environ.get("PNYOLO_GROUP", "1") != "0" and torch.is_grad_enabled() and self.training
+                and (self.trainable_mlp_parameters() or self._latent_src is not None)):
+            # Training on a super-batch: ONE grouped scene (pny_scene_set_groups) holds every object's views, so that each MLP
+            # pass of the render and of its backward is one launch over all objects' tiles (the reference flattens the
+            # super-batch the same way, nerf.py:283-288).  The per-object handles are filled only if something asks for them.
+            if self._h_group is None:
+                self._h_group = self._new_scene()
+            g = self._h_group
+
+            def all_rows(t):
+                return torch.cat([self._cam_rows(t, sb, SB, NS).expand(NS, 2) for sb in range(SB)], dim=0).contiguous()
+            f_all, c_all = all_rows(focal), all_rows(c)
+            check(L.pny_scene_set_cameras(g, ptr(poses_h), SB * NS, ptr(f_all), SB * NS, ptr(c_all), SB * NS, W, H))
+            check(L.pny_scene_set_groups(g, SB))
+            if latent is not None:
+                check(L.pny_scene_set_latent(g, ptr(latent), SB * NS, latent.shape[1], latent.shape[2], latent.shape[3], st))
+            else:
+                check(L.pny_scene_encode(g, ptr(images), SB * NS, H, W, st))
+            self._group = dict(SB=SB, NS=NS)
+            self._scenes_pending = dict(poses=poses_h, focal=focal, c=c, W=W, H=H)
+            return
         scenes = [self._scene(sb) for sb in range(SB)]
         # the library's trunk over a super-batch: ONE pass over all SB * NS images (as the reference's encode flattens them),
         # cameras per scene below
@@ -681,16 +767,7 @@ class PixelNeRFNet(nn.Module):
           with torch.cuda.stream(streams[sb]):
             s = scenes[sb]
             st = stream_of(dev)
-            # per-scene focal / c rows: batch 1 broadcasts, batch SB is per scene, batch SB*NS per view
-            def rows(t):
-                if t.shape[0] == 1:
-                    return t[:1]
-                if t.shape[0] == SB * NS:
-                    return t[sb * NS:(sb + 1) * NS]
-                if t.shape[0] == SB:
-                    return t[sb:sb + 1]
-                raise ValueError("focal / c batch must be 1, SB or SB*NS")
-            f_s, c_s = rows(focal).contiguous(), rows(c).contiguous()
+            f_s, c_s = self._cam_rows(focal, sb, SB, NS).contiguous(), self._cam_rows(c, sb, SB, NS).contiguous()
             p_s = poses_h[sb * NS:(sb + 1) * NS].contiguous()
             check(L.pny_scene_set_cameras(s, ptr(p_s), NS, ptr(f_s), f_s.shape[0], ptr(c_s), c_s.shape[0], W, H))
             if latent is not None:
@@ -728,7 +805,7 @@ class PixelNeRFNet(nn.Module):
     def latent(self, sb=0):
         """(NS, L, Hl, Wl) latent of scene `sb` as the reference keeps it in encoder.latent."""
         L = _lib.load()
-        s = self._h_scenes[sb]
+        s = self._scene(sb)
         dims = [C.c_int() for _ in range(4)]
         check(L.pny_scene_latent_shape(s, *[C.byref(d) for d in dims]))
         out = torch.empty([d.value for d in dims], device=self._device(), dtype=torch.float32)

@@ -272,7 +272,28 @@ class _RenderFunction(torch.autograd.Function):
         # d loss / d latent, accumulated by every scene's call into its own slice (channel-last).  Its zero fill runs on the
         # current stream, so it is enqueued BEFORE the side streams fork from that stream: scenes 1.. add into the buffer
         # with atomics from their own streams, and nothing else would order those behind the fill.
-        lat_grad = model.begin_latent_grad(ctx.lat_meta, SB) if ctx.lat_meta is not None else None
+        group = bool(sv.get("group"))
+        if group and not deferred:
+            raise RuntimeError("the grouped training forward lost its stash reservation (another training forward ran before "
+                               "this backward): call backward() before the next forward, or set PNYOLO_GROUP=0")
+        lat_grad = model.begin_latent_grad(ctx.lat_meta, SB, group=group) if ctx.lat_meta is not None else None
+        if group:   # one call over the SB * B rays on the grouped scene (see NeRFRenderer._render)
+            s_ = _lib.RenderSaved(z_coarse=sv["z_coarse"].data_ptr(), sample_coarse=sv["sample_coarse"].data_ptr())
+            if not getattr(ren, "_detach_fine_depth", False):
+                s_.depth_coarse = sv["depth_coarse"].data_ptr()
+            if ctx.has_fine:
+                s_.z_fine = sv["z_fine"].data_ptr()
+                s_.sample_fine = sv["sample_fine"].data_ptr()
+            g_ = _lib.RenderGrads(*[None if p is None else p.data_ptr() for p in ups])
+            check(L.pny_render_backward(model._h_group, ptr(sv["rays"]), SB * B, C.byref(sv["opts"][0]), C.byref(s_), C.byref(g_),
+                                        acc, stream_of(dev)))
+            extra = () if lat_grad is None else (model.end_latent_grad(lat_grad, ctx.lat_meta, SB, group=True),)
+            if lat_grad is not None:
+                model._lat_grad_event = torch.cuda.Event()
+                model._lat_grad_event.record(torch.cuda.current_stream(dev))
+            check(L.pny_model_flush_weight_grads(model._h_model, 1, stream_of(dev)))
+            check(L.pny_model_defer_weight_grads(model._h_model, 0, 0, 0, 0))
+            return (None, None, None, None, None) + tuple(grads) + extra
         streams = model.fork_streams(SB) if deferred else [None] * SB
         calls = []
         for sb in range(SB):
@@ -427,6 +448,54 @@ class NeRFRenderer(torch.nn.Module):
         draws, self.draws = self.draws, None
         self._calls += 1
         keep = []
+        # Training on a super-batch held by ONE grouped scene (model.encode, pny_scene_set_groups): a single pny_render over
+        # the SB * B rays -- one MLP launch per pass over every object's tiles instead of SB launches on side streams.  Needs
+        # whole 64-sample tiles per object in both passes; otherwise the per-object path below (model._scene fills its handles).
+        model._last_call_group = False
+        g = model._group_scene() if stash else None
+        if (g is not None and SB == model._group["SB"] and (B * kc) % 64 == 0 and (not use_fine or (B * (kc + kf)) % 64 == 0)
+                and not extra):
+            o = RenderOpts(n_coarse=kc, n_fine=kf, n_fine_depth=kfd, depth_std=float(self.depth_std),
+                           white_bkgd=int(bool(self.white_bkgd)), lindisp=int(bool(self.lindisp)),
+                           seed=(self.base_seed + 7919 * self._calls) & 0xFFFFFFFFFFFFFFFF)
+
+            def flat(name, cols, scale=None):
+                if cols == 0:
+                    return None
+                if draws is not None and name in draws:
+                    t = torch.as_tensor(draws[name], dtype=torch.float32).reshape(SB * B, cols).to(dev)
+                elif scale is not None:
+                    t = torch.randn(SB * B, cols, device=dev, dtype=torch.float32)
+                else:
+                    return None
+                t = (t * scale if scale is not None else t).contiguous()
+                keep.append(t)
+                return t.data_ptr()
+            if draws is not None:
+                o.u_coarse_dev = flat("u_coarse", kc)
+                o.u_fine_dev = flat("u_fine", kf - kfd)
+                o.u_fine2_dev = flat("u_fine2", kf - kfd)
+                o.g_depth_dev = flat("g_depth", kfd)
+            if self.training and self.noise_std > 0.0:
+                o.sigma_noise_coarse_dev = flat("noise_coarse", kc, float(self.noise_std))
+                if use_fine:
+                    o.sigma_noise_fine_dev = flat("noise_fine", kc + kf, float(self.noise_std))
+            out = RenderOut()
+            out.rgb_coarse, out.depth_coarse = res["coarse"]["rgb"].data_ptr(), res["coarse"]["depth"].data_ptr()
+            if want_weights:
+                out.weights_coarse = res["coarse"]["weights"].data_ptr()
+            if use_fine:
+                out.rgb_fine, out.depth_fine = res["fine"]["rgb"].data_ptr(), res["fine"]["depth"].data_ptr()
+                if want_weights:
+                    out.weights_fine = res["fine"]["weights"].data_ptr()
+            for name in ("z_coarse", "sample_coarse", "z_fine", "sample_fine"):
+                if name in saved:
+                    setattr(out, name, saved[name].data_ptr())
+            saved["opts"], saved["keep"], saved["group"] = [o], keep, True
+            check(L.pny_scene_stash_next_render(g, 1))
+            check(L.pny_render(g, ptr(rays), SB * B, C.byref(o), C.byref(out), stream_of(dev)))
+            model._last_call_group = True
+            return res, saved
         streams = model.fork_streams(SB)      # scenes are independent: one side stream each (None = current stream)
         for sb in range(SB):
             with torch.cuda.stream(streams[sb]):

@@ -37,7 +37,7 @@ def test_abi_exports_every_declared_symbol(built_lib):
     assert declared == set(plib.SIGNATURES.keys()), declared ^ set(plib.SIGNATURES.keys())
     for name in declared:
         assert hasattr(built_lib, name)
-    assert built_lib.pny_version() == plib.ABI_VERSION == 10
+    assert built_lib.pny_version() == plib.ABI_VERSION == 11
 
 
 def test_no_gpu_is_loud(built_lib):

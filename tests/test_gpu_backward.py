@@ -487,13 +487,16 @@ def test_device_refresh_equals_full_reupload():
     assert not torch.equal(stale, fresh)
 
 
-@pytest.mark.parametrize("streams", ["1", "0", "split"])
+@pytest.mark.parametrize("streams", ["group", "1", "0", "split"])
 def test_render_backward_super_batch(streams, monkeypatch):
-    """SB = 3 scenes x B rays (the reference's training batch shape): the scenes' backward calls append to one
-    model-level stash (deferred weight gradients, side streams unless PNYOLO_SCENE_STREAMS=0) and one weight-gradient
-    GEMM per MLP sums over all of them; against the sum of the oracle's per-scene gradients."""
+    """SB = 3 scenes x B rays (the reference's training batch shape) against the sum of the oracle's per-scene gradients.
+    "group" (the default): ONE grouped scene holds the super-batch (pny_scene_set_groups), one launch per MLP pass over all
+    objects' tiles, forward and backward.  The others (PNYOLO_GROUP=0): one scene per object, whose backward calls append to
+    one model-level stash (deferred weight gradients, side streams unless PNYOLO_SCENE_STREAMS=0) with one weight-gradient
+    GEMM per MLP over all of them."""
     # "split": every scene's fine pass, mlp_fine's flush on its own stream, then the coarse passes (pny_render_backward bits 4 / 8)
-    monkeypatch.setenv("PNYOLO_SCENE_STREAMS", "1" if streams == "split" else streams)
+    monkeypatch.setenv("PNYOLO_GROUP", "1" if streams == "group" else "0")
+    monkeypatch.setenv("PNYOLO_SCENE_STREAMS", "0" if streams == "0" else "1")
     monkeypatch.setenv("PNYOLO_SPLIT_FLUSH", "1" if streams == "split" else "0")
     SB, ns, H, W, kc, kf, kfd, n = 3, 2, 32, 32, 16, 8, 4, 24
     c = pconf.default_mv()
@@ -538,6 +541,73 @@ def test_render_backward_super_batch(streams, monkeypatch):
     ref_loss.backward()
     sc0 = scs[0]
     compare_param_grads(net, sc0)
+    assert net._last_call_group == (streams == "group")
+
+
+@pytest.mark.parametrize("lat_grad", [False, True])
+def test_grouped_super_batch_equals_per_object(lat_grad, monkeypatch):
+    """The grouped scene (one launch per MLP pass over all objects' tiles) against one scene per object on the same batch:
+    the same tiles through the same kernels -- rendered outputs bit-equal, parameter (and latent) gradients equal to fp32
+    summation order; per-view intrinsics; a batch whose shares are not whole tiles falls back to the per-object path; the
+    per-object handles are filled on demand after a grouped encode()."""
+    SB, ns, H, W, kc, kf, kfd, n = 4, 3, 32, 32, 16, 8, 4, 16
+    c = pconf.default_mv()
+    rs = np.random.RandomState(5)
+    lat = np.concatenate([synth.latent(1510 + i, ns, 512, H // 2, W // 2) for i in range(SB)])
+    poses = np.stack([synth.scene_cameras(ns, radius=1.3 + 0.05 * i)[0] for i in range(SB)])
+    focal = torch.from_numpy(rs.uniform(26.0, 31.0, size=(SB * ns, 2)).astype(np.float32))     # per view
+    cc = torch.from_numpy(rs.uniform(14.0, 18.0, size=(SB, 2)).astype(np.float32))              # per object
+    rays = torch.stack([orc.gen_rays(synth.pose_spherical(100.0 + 25 * i, -20.0, 1.3)[None], W, H, 29.0, 0.3, 1.8)[0]
+                        .reshape(-1, 8)[torch.from_numpy(rs.choice(H * W, n, replace=False))] for i in range(SB)])
+    dr = dict(u_coarse=rs.rand(SB * n, kc).astype(np.float32), u_fine=rs.rand(SB * n, kf - kfd).astype(np.float32),
+              u_fine2=rs.rand(SB * n, kf - kfd).astype(np.float32), g_depth=rs.randn(SB * n, kfd).astype(np.float32))
+    gt = torch.from_numpy(rs.uniform(0, 1, size=(SB, n, 3)).astype(np.float32)).to(DEV)
+
+    def run(group, nrays=n):
+        monkeypatch.setenv("PNYOLO_GROUP", "1" if group else "0")
+        net = make_model(c["model"], stop_encoder_grad=True)
+        load_mlp(net.mlp_coarse, 1501, 512, 4)
+        load_mlp(net.mlp_fine, 1502, 512, 4)
+        net = net.to(DEV).train()
+        lt = torch.from_numpy(lat).to(DEV).requires_grad_(lat_grad)
+        net.encode(torch.zeros(SB, ns, 3, H, W), torch.from_numpy(poses), focal, c=cc, latent=lt)
+        assert (net._group is not None) == group
+        ren = NeRFRenderer(n_coarse=kc, n_fine=kf, n_fine_depth=kfd, white_bkgd=True).train()
+        ren.draws = {k: v.reshape(SB, n, -1)[:, :nrays].reshape(SB * nrays, -1) for k, v in dr.items()}
+        out = ren(net, rays[:, :nrays].to(DEV), want_weights=True)
+        (torch.nn.functional.mse_loss(out["coarse"]["rgb"], gt[:, :nrays]) + torch.nn.functional.mse_loss(out["fine"]["rgb"], gt[:, :nrays])
+         + 0.1 * out["fine"]["depth"].mean()).backward()
+        torch.cuda.synchronize()
+        grads = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+        if lat_grad:
+            grads["latent"] = lt.grad.clone()
+        flat = {q + "." + k: v.detach().clone() for q in ("coarse", "fine") for k, v in out[q].items()}
+        return net, flat, grads
+
+    net_g, out_g, grad_g = run(True)
+    assert net_g._last_call_group
+    _, out_s, grad_s = run(False)
+    for k in out_s:
+        assert torch.equal(out_g[k], out_s[k]), k
+    assert len(grad_g) == len(grad_s) >= 60
+    for k in grad_s:
+        scale = float(grad_s[k].abs().max())
+        assert float((grad_g[k] - grad_s[k]).abs().max()) <= 2e-6 * max(scale, 1e-20), k
+    # per-object handles on demand: a query after the grouped encode sees the same scenes
+    xyz = torch.from_numpy(rs.uniform(-0.3, 0.3, size=(SB, 7, 3)).astype(np.float32)).to(DEV)
+    vd = torch.nn.functional.normalize(torch.from_numpy(rs.standard_normal((SB, 7, 3)).astype(np.float32)), dim=-1).to(DEV)
+    with torch.no_grad():
+        q_g = net_g(xyz, coarse=True, viewdirs=vd)
+    net_s, _, _ = run(False)
+    with torch.no_grad():
+        q_s = net_s(xyz, coarse=True, viewdirs=vd)
+    assert torch.equal(q_g, q_s)
+    # shares that are not whole tiles (15 rays x 16 samples): the grouped encode is there, the call takes the per-object path
+    net_r, out_r, _ = run(True, nrays=15)
+    assert net_r._group is not None and not net_r._last_call_group
+    _, out_r0, _ = run(False, nrays=15)
+    for k in out_r0:
+        assert torch.equal(out_r[k], out_r0[k]), k
 
 
 def test_yolo_render_backward_vs_oracle():
