@@ -523,7 +523,8 @@ class PixelNeRFNet(nn.Module):
     def last_launch_f16x2(self, scene=0):
         """True when the last MLP launch of scene `scene` ran the f16x2 kernel."""
         v = C.c_int(0)
-        check(_lib.load().pny_scene_last_precision(self._scene(scene), C.byref(v)))
+        h = self._h_group if (self._last_call_group and self._group is not None) else self._scene(scene)
+        check(_lib.load().pny_scene_last_precision(h, C.byref(v)))
         return bool(v.value)
 
     def project_latent(self):
@@ -837,6 +838,7 @@ class PixelNeRFNet(nn.Module):
         SB, B, _ = xyz.shape
         assert SB == self.num_objs, "super-batch of xyz must match the encoded scenes"
         assert viewdirs is not None, "use_viewdirs is set: viewdirs are required"
+        self._last_call_group = False
         xyz = xyz.detach().to(dev, torch.float32).contiguous()
         viewdirs = viewdirs.detach().to(dev, torch.float32).reshape(SB, B, 3).contiguous()
         out = torch.empty(SB, B, self.d_out, device=dev, dtype=torch.float32)
