@@ -263,6 +263,7 @@ def train_main(args):
     if os.environ.get("PNYOLO_BENCH_NO_GC"):   # diagnostic: is the periodic slow step the collector?
         import gc
         gc.disable()
+    net.enable_kernel_timing(True)   # before the warm-up: the library creates its HIP events on the first timed call (~1.5 ms)
     for i in range(max(args.warmup, 4)):
         l0 = step(i)
     fence()
@@ -272,7 +273,6 @@ def train_main(args):
     import gc
     gc.collect()
     gc.freeze()
-    net.enable_kernel_timing(True)
     k_ms, k_fl = [0.0] * 4, [0.0] * 4
     prof = None
     if os.environ.get("PNYOLO_BENCH_HOST_PROFILE"):   # diagnostic: cProfile of the timed loop on stderr
