@@ -330,7 +330,7 @@ def train_main(args):
                                    if args.train_encoder else "frozen ResNet34 trunk encoded every step"),
                    "rays_per_step": world * SB * RB, "rays_per_step_this_rank": SB * RB,
                    "parallelism": "dp%d: one super-batch per rank, 1 gradient all-reduce (27 MB fp32) per step" % world},
-        "loss_first": float(l0), "loss_last": float(loss),
+        "loss_first": float(l0.detach()), "loss_last": float(loss.detach()),
         "roofline": {"bound": "mfma", "kernel": "MLP kernels of a training step", "achieved": tot_fl / (tot_ms * 1e-3) / 1e12,
                      "peak": train_peak, "unit": "TFLOP/s", "frac": tot_fl / (tot_ms * 1e-3) / 1e12 / train_peak,
                      "x_fp32_mfma_peak": tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,

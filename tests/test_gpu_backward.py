@@ -360,7 +360,7 @@ def test_training_step_updates_weights():
         opt.zero_grad()
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert losses[-1] < losses[0], losses
 
 
@@ -537,7 +537,7 @@ def test_render_backward_super_batch(streams, monkeypatch):
         ref_c.append(r["coarse"]["rgb"])
         ref_f.append(r["fine"]["rgb"])
     ref_loss = torch.nn.functional.mse_loss(torch.stack(ref_c), gt) + torch.nn.functional.mse_loss(torch.stack(ref_f), gt)
-    assert abs(float(loss) - float(ref_loss)) < 1e-5
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) < 1e-5
     ref_loss.backward()
     sc0 = scs[0]
     compare_param_grads(net, sc0)
