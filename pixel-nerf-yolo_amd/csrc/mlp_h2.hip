@@ -97,15 +97,20 @@ __device__ __forceinline__ void h2group_sync(unsigned* cnt, unsigned& epoch, int
 // `bias`: a 512-float vector of the workgroup's LDS bias table.
 // Stores into the tile's record of the X stash go through a raw buffer resource with 32-bit offsets (64-bit pointers per
 // accumulator quad cost 32 address registers per epilogue).  The whole offset travels in the VGPR, the scalar offset stays
-// the constant 0.  With the slot offset in an SGPR soffset the compiler placed VALU writes of the store's first data register
-// directly behind the store (it treats that form as hazard-free) and inside this kernel the first dword of ~20 % of those
-// stores carried the NEW value (lin_in / lin_z weight gradients off by 1-3 %, in exactly the `.x` columns); with the constant
-// form LLVM's hazard recogniser inserts the wait state and the stash is exact.  In isolation only the constant form shows the
-// hazard (tools/ubench/lds_write_data_hazard.hip), so what else contributed here is open; this form is the safe one.
+// the constant 0: a buffer store of more than 64 bits needs ONE wait state before a VALU write of its data registers, LLVM's
+// hazard recogniser inserts it only when soffset is not a register, and gfx950 needs it with an SGPR soffset too -- with the
+// slot offset in an SGPR the compiler put the next write of the first data register directly behind 8 of these stores (the
+// x_in and z operands) and ~20 % of them carried the NEW value in dword 0 (lin_in / lin_z weight gradients off by 1-9 %, in
+// exactly the `.x` columns).  One `s_nop 0` behind the store cures that form (profiles/r03_anomalies.md B;
+// tools/check_store_hazard.py guards the built library against the pattern).
 __device__ __forceinline__ void stash_store(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, float a, float b, float c, float d) {
     const f32x4 v = {a, b, c, d};
-#ifdef PNY_H2_ANOM_SOFF   // diagnosis only (profiles/r03_anomalies.md): the form that fails -- slot offset in the SGPR soffset
+#ifdef PNY_H2_ANOM_SOFF   // diagnosis only (profiles/r03_anomalies.md): the form the compiler does not guard -- slot offset in the SGPR soffset
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, voff, __builtin_amdgcn_readfirstlane(soff), 0);
+#ifdef PNY_H2_ANOM_SOFF_NOP   // ... and the one wait state the compiler does not insert for this form, by hand
+    asm volatile("s_nop 0" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 #else
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, voff + soff, 0, 0);
 #endif
