@@ -328,6 +328,8 @@ def train_main(args):
                                     % ("ATen graph forward / backward (PNYOLO_TRUNK=torch)" if os.environ.get("PNYOLO_TRUNK") == "torch"
                                        else "this library's training kernels forward / backward (csrc/encoder_train.hip)"))
                                    if args.train_encoder else "frozen ResNet34 trunk encoded every step"),
+                   "super_batch": ("one grouped scene: one launch per MLP pass over all objects' tiles (pny_scene_set_groups)"
+                                   if net._group is not None else "one scene per object, launches on side streams"),
                    "rays_per_step": world * SB * RB, "rays_per_step_this_rank": SB * RB,
                    "parallelism": "dp%d: one super-batch per rank, 1 gradient all-reduce (27 MB fp32) per step" % world},
         "loss_first": float(l0.detach()), "loss_last": float(loss.detach()),
