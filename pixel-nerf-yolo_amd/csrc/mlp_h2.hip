@@ -85,8 +85,16 @@ __device__ __forceinline__ void h2group_sync(unsigned* cnt, unsigned& epoch, int
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 #define H2SYNC() h2group_sync(sync_cnt, sync_epoch, wave, lane)
+#define H2SYNC_P() H2SYNC()
+#elif defined(PNY_H2_EXP_NOSYNC)
+// Timing-only experiment (wrong results): every workgroup barrier except the two around the prologue (the tap table must be
+// valid: it holds addresses) removed -- the waves of a workgroup free-run through a view's GEMMs, epilogues and gathers.  An
+// UPPER bound for what replacing the barriers by data-flow flags (rows written / rows read) can return.
+#define H2SYNC()
+#define H2SYNC_P() __syncthreads()
 #else
 #define H2SYNC() __syncthreads()
+#define H2SYNC_P() H2SYNC()
 #endif
 
 // The 8-byte slot of feature quad (row, half) = (feature / 8, (feature / 4) & 1) of sample m in plane p is at byte
@@ -445,10 +453,10 @@ __global__ __launch_bounds__(h2::THREADS, 2) void PNY_H2_KERNEL(const MlpArgs a)
             const unsigned x_view = STASH ? (unsigned)v * (unsigned)a.lay.x_view * 4u : 0u;
             auto act_slot = [&](int i) { return x_view + ((unsigned)a.lay.x_act + (unsigned)i * (unsigned)STASH_SLOT) * 4u; };
             HS_T0();
-            H2SYNC();
+            H2SYNC_P();
             h2prologue<STASH>(a, v, tile, planes, tap_tab, tid, a.range_flag, xr, x_view + (unsigned)a.lay.x_in * 4u, tap_raw);
             h2zero<NT, MT>(h);
-            H2SYNC();
+            H2SYNC_P();
             if constexpr (STASH) {
                 // z = the interpolated latent of this view (reference encoder.py:101), the B operand of lin_z's weight
                 // gradient: gathered from the latent itself, 128 channels at a time, two chunks in flight, written straight
@@ -582,7 +590,7 @@ __global__ __launch_bounds__(h2::THREADS, 2) void PNY_H2_KERNEL(const MlpArgs a)
                 else if (o == 3)
                     sum = fmaxf(sum, 0.f);
             }
-#ifdef PNY_H2_EXP_STAGGER
+#if defined(PNY_H2_EXP_STAGGER) || defined(PNY_H2_EXP_NOSYNC)
             if (!(fabsf(sum) < 1e3f)) sum = 0.5f;   // (timing experiment: keep the garbage finite so that the fine pass samples real points)
 #endif
             const long long s = tile * TM + m;
