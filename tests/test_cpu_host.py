@@ -56,6 +56,30 @@ def test_no_wide_store_with_sgpr_soffset_is_followed_by_a_write_of_its_data(buil
         assert objs, "no gfx950 code object in the library"
         bad = [b for o in objs for b in chk.scan(o)]
     assert not bad, bad[:3]
+    # the scanner itself, on the two ISA shapes of profiles/r03_anomaly_b_isa.txt (failing) and on the guarded forms
+    listing = """
+0000000000001900 <kernel_a>:
+	buffer_store_dwordx4 v[2:5], v19, s[60:63], s41 offen          // 000000001900: E07C1000
+	v_and_b32_e32 v2, 0x3800, v11                                   // 000000001908: 260416FF
+	buffer_store_dwordx4 v[88:91], v232, s[60:63], s8 offen        // 000000001910: E07C1000
+	s_nop 0                                                         // 000000001918: BF800000
+	v_mul_f32_e32 v88, v2, v34                                      // 00000000191C: 0AB04502
+	buffer_store_dwordx4 v[88:91], v232, s[60:63], 0 offen         // 000000001920: E07C1000
+	v_mul_f32_e32 v88, v2, v34                                      // 000000001928: 0AB04502
+	buffer_store_dwordx4 v[10:13], v232, s[60:63], s8 offen        // 000000001930: E07C1000
+	v_mul_f32_e32 v14, v2, v34                                      // 000000001938: 0AB04502
+"""
+    import subprocess
+    real_run = subprocess.run
+
+    class _R:
+        stdout = listing
+    try:
+        chk.subprocess.run = lambda *a, **k: _R()
+        hits = chk.scan("unused")
+    finally:
+        chk.subprocess.run = real_run
+    assert len(hits) == 1 and hits[0][0] == "kernel_a" and "v[2:5]" in hits[0][1] and hits[0][2].startswith("v_and_b32")
 
 
 def test_no_gpu_is_loud(built_lib):
