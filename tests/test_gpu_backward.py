@@ -610,6 +610,48 @@ def test_grouped_super_batch_equals_per_object(lat_grad, monkeypatch):
         assert torch.equal(out_r[k], out_r0[k]), k
 
 
+def test_grouped_scene_through_the_abi(monkeypatch):
+    """pny_scene_set_groups at the C ABI, without the Python render path: pny_query on a grouped scene (points in n_objs equal
+    shares, whole 64-point tiles each) returns what the per-object scenes return, bit for bit, with a 1792-channel latent
+    (the YOLO backbone's width) as well; shares that are not whole tiles and a view count the objects do not divide are refused
+    with PNY_ERR_ARG / PNY_ERR_STATE."""
+    import ctypes as C
+    L_ = plib.load()
+    rs = np.random.RandomState(9)
+    for d_lat, hw in ((512, 16), (1792, 16)):   # (maps of >= 256 pixels per object: the same projection kernel both ways)
+        SB, ns, H, W, B = 3, 2, 32, 32, 128
+        monkeypatch.setenv("PNYOLO_GROUP", "1")
+        conf = pconf.default_mv()
+        if d_lat != 512:
+            conf.d["model"]["encoder"]["backbone"] = "custom"
+        net = make_model(conf["model"], stop_encoder_grad=True)
+        load_mlp(net.mlp_coarse, 1601, d_lat, 4)
+        load_mlp(net.mlp_fine, 1602, d_lat, 4)
+        net = net.to(DEV).train()
+        net.set_latent_projection("on")   # (AUTO decides by the launch's point count: 384 grouped against 128 per object)
+        lat = torch.from_numpy(np.concatenate([synth.latent(1610 + i, ns, d_lat, hw, hw) for i in range(SB)])).to(DEV)
+        poses = torch.from_numpy(np.stack([synth.scene_cameras(ns, radius=1.3 + 0.05 * i)[0] for i in range(SB)]))
+        net.encode(torch.zeros(SB, ns, 3, H, W), poses, torch.tensor(29.0), latent=lat)     # train mode: the grouped handle
+        g = net._group_scene()
+        assert g is not None
+        xyz = torch.from_numpy(rs.uniform(-0.4, 0.4, size=(SB, B, 3)).astype(np.float32)).to(DEV)
+        vd = torch.nn.functional.normalize(torch.from_numpy(rs.standard_normal((SB, B, 3)).astype(np.float32)), dim=-1).to(DEV)
+        out_g = torch.empty(SB, B, 4, device=DEV)
+        st = plib.stream_of(torch.device(DEV))
+        plib.check(L_.pny_query(g, plib.ptr(xyz), plib.ptr(vd), SB * B, 1, plib.ptr(out_g), st))
+        with torch.no_grad():
+            out_s = net(xyz, coarse=True, viewdirs=vd)                                      # per-object handles, filled on demand
+        torch.cuda.synchronize()
+        assert torch.equal(out_g, out_s), (d_lat, float((out_g - out_s).abs().max()))
+        # refused: shares of 100 points (not whole tiles); 3 objects over a scene regrouped into 4
+        rc = L_.pny_query(g, plib.ptr(xyz), plib.ptr(vd), SB * 100, 1, plib.ptr(out_g), st)
+        assert rc == -1 and b"multiple of 64" in L_.pny_last_error()
+        plib.check(L_.pny_scene_set_groups(g, 4))
+        rc = L_.pny_query(g, plib.ptr(xyz), plib.ptr(vd), 4 * 64, 1, plib.ptr(out_g), st)
+        assert rc != 0 and b"not a multiple of the object count" in L_.pny_last_error()
+        plib.check(L_.pny_scene_set_groups(g, SB))
+
+
 def test_yolo_render_backward_vs_oracle():
     """YoloRenderer under autograd (the fork's own training path, YoloTrainer.py:160-186): probability-weighted
     aggregation along the ray (yolo.py:96-114) + raw 21-vector MLP, L = 1792, against autograd through the oracle."""
