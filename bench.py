@@ -230,6 +230,8 @@ def train_main(args):
         for p_ in net.encoder.parameters():
             p_.requires_grad_(False)
     ren = NeRFRenderer(n_coarse=KC, n_fine=KF, n_fine_depth=KFD, depth_std=0.01, white_bkgd=True).train()
+    if os.environ.get("PNYOLO_BENCH_SEED"):   # diagnostic: another stream of sampling jitter
+        ren.base_seed = int(os.environ["PNYOLO_BENCH_SEED"])
     par = ren.bind_parallel(net, None).train()
     opt = torch.optim.Adam([p_ for p_ in net.parameters() if p_.requires_grad], lr=1e-4)
     params = [p_ for p_ in net.parameters() if p_.requires_grad]
@@ -281,8 +283,11 @@ def train_main(args):
         prof.enable()
     t0 = time.perf_counter()
     step_ms, t_prev = [], t0
+    curve = []
     for i in range(steps):
         loss = step(100 + i)
+        if os.environ.get("PNYOLO_BENCH_LOSSES"):   # diagnostic: the loss of every step (device scalars, read after the loop)
+            curve.append(loss.detach())
         f = net.last_mlp_stats(full=True)     # NOTE: reading event times waits for the step
         b = net.last_backward_stats()
         k_ms[0] += f["kernel_ms"]
@@ -345,6 +350,8 @@ def train_main(args):
     }
     if os.environ.get("PNYOLO_BENCH_STEP_TIMES"):
         out["step_ms"] = step_ms
+    if curve:
+        out["loss_curve"] = [round(float(x), 5) for x in curve]
     if args.rehearse_one_gpu:
         out["rehearsal"] = "ranks share ONE GPU, gloo transport: mechanics check, not a measurement"
     if rank == 0:
