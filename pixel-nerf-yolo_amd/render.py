@@ -54,9 +54,13 @@ class _MultiDeviceRenderWrapper(torch.nn.Module):
         without waiting, and gathers the tiles on ``gpus[0]`` with peer copies.
     Results: a ray renders to the same bits whatever range it is in (slice invariance), so with explicit draws
     the assembled output equals the single-device call bit for bit; with Philox draws each range has its own seed.
-    Training calls (grad mode, trainable parameters) run on ``gpus[0]`` alone: data-parallel training in this framework is
-    one process per GPU (dist.allreduce_gradients); the call sites still run unchanged.  dist.py stays the recommended
-    multi-GPU path (no Python serialisation of the per-device launches)."""
+    Training calls (grad mode, trainable MLP parameters, frozen encoder -- ``train.py --freeze_enc``) split the same way
+    (_train_split): every device runs the training forward and backward of its ray range on its replica, the replica's
+    parameters enter the graph as device copies of the master's (``p.to(device)``: autograd carries each device's gradients back
+    and sums them into the master's ``.grad``, as DataParallel's replicate / gather do), and the replicas pick the stepped
+    weights up at the next call.  With a trainable encoder (a latent that takes a gradient) the call runs on ``gpus[0]`` alone.
+    dist.py (one process per GPU, one gradient all-reduce) stays the recommended multi-GPU path: no Python serialisation of
+    the per-device launches."""
 
     def __init__(self, net, renderer, gpus, simple_output):
         super().__init__()
@@ -79,6 +83,8 @@ class _MultiDeviceRenderWrapper(torch.nn.Module):
                 r.mlp_fine = None
             r.load_state_dict(net.state_dict(), strict=False)
             r = r.to(dev).eval()
+            for (_, pr), (_, pm) in zip(r.named_parameters(), net.named_parameters()):
+                pr.requires_grad_(pm.requires_grad)
             r._projection, r._precision = net._projection, net._precision
             self._replicas[i] = r
         key = (net._weights_key(), net._encode_epoch)
@@ -92,6 +98,7 @@ class _MultiDeviceRenderWrapper(torch.nn.Module):
             le = net._last_encode
             if le is None:
                 raise RuntimeError("bind_parallel(net, gpus): call net.encode(...) before rendering")
+            r.train(net.training)          # (a training master: the replica's encode() fills its grouped scene too)
             with torch.cuda.device(dev):
                 lat = torch.cat([net.latent(sb) for sb in range(le["SB"])]).to(dev)
                 images = torch.zeros(le["SB"], le["NS"], 3, le["H"], le["W"])
@@ -107,11 +114,14 @@ class _MultiDeviceRenderWrapper(torch.nn.Module):
         training = torch.is_grad_enabled() and net.training and (net.trainable_mlp_parameters() or net.differentiable_latent() is not None)
         B = rays.shape[1]
         n_dev = len(self.gpus)
-        if training or B < 64 * n_dev:
-            if training and not self._warned:
+        if training and B >= 64 * n_dev and net.differentiable_latent() is None and net.trainable_mlp_parameters():
+            outputs = self._train_split(rays, want_weights)
+        elif training or B < 64 * n_dev:
+            if training and B >= 64 * n_dev and not self._warned:
                 import warnings
-                warnings.warn("bind_parallel(net, gpus=%s): training calls run on cuda:%d alone (data-parallel training is one "
-                              "process per GPU here: pixel_nerf_yolo_amd.dist)" % (self.gpus, self.gpus[0]))
+                warnings.warn("bind_parallel(net, gpus=%s): training calls with a trainable encoder run on cuda:%d alone "
+                              "(data-parallel training of the whole model is one process per GPU here: "
+                              "pixel_nerf_yolo_amd.dist)" % (self.gpus, self.gpus[0]))
                 self._warned = True
             outputs = ren(net, rays, want_weights=want_weights)
         else:
@@ -120,6 +130,47 @@ class _MultiDeviceRenderWrapper(torch.nn.Module):
             part = outputs["fine"] if "fine" in outputs else outputs["coarse"]
             return part["rgb"], part["depth"]
         return outputs
+
+    def _train_split(self, rays, want_weights):
+        """Training call over several devices (see the class docstring): _RenderFunction per device on its replica, with
+        differentiable device copies of the master's parameters as the graph's leaves."""
+        net, ren = self.net, self.renderer
+        SB, B = rays.shape[0], rays.shape[1]
+        n_dev = len(self.gpus)
+        per = -(-B // n_dev)
+        per = -(-per // 64) * 64
+        bounds = [(min(B, i * per), min(B, (i + 1) * per)) for i in range(n_dev)]
+        named = net.trainable_mlp_parameters()
+        kf = int(ren.n_fine) if (ren.using_fine and ren.n_fine > 0) else 0
+        draws, calls = ren.draws, ren._calls
+        ren.draws = None
+        dev0 = torch.device("cuda", self.gpus[0])
+        parts = []
+        try:
+            for i, (lo, hi) in enumerate(bounds):
+                if hi <= lo:
+                    continue
+                r = self._replica(i)
+                r.train()
+                dev = torch.device("cuda", self.gpus[i])
+                with torch.cuda.device(dev):
+                    ren._calls = calls + i
+                    if draws is not None:
+                        ren.draws = {k: torch.as_tensor(v).reshape(SB, B, -1)[:, lo:hi].reshape(SB * (hi - lo), -1) for k, v in draws.items()}
+                    leaves = [p if p.device == dev else p.to(dev) for _, p in named]
+                    outs = _RenderFunction.apply(ren, r, rays[:, lo:hi].to(dev), kf > 0, len(leaves), *leaves)
+                parts.append([o.to(dev0) for o in outs])
+        finally:
+            ren._calls, ren.draws = calls + n_dev, None
+        cat = [torch.cat([p[j] for p in parts], dim=1) if parts[0][j].numel() else parts[0][j] for j in range(6)]
+        res = {"coarse": {"rgb": cat[0], "depth": cat[1]}}
+        if want_weights:
+            res["coarse"]["weights"] = cat[2]
+        if kf > 0:
+            res["fine"] = {"rgb": cat[3], "depth": cat[4]}
+            if want_weights:
+                res["fine"]["weights"] = cat[5]
+        return res
 
     def _render_split(self, rays, want_weights):
         net, ren = self.net, self.renderer

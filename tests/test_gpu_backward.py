@@ -652,6 +652,61 @@ def test_grouped_scene_through_the_abi(monkeypatch):
         plib.check(L_.pny_scene_set_groups(g, SB))
 
 
+def test_bind_parallel_training_on_several_devices():
+    """The reference's multi-GPU training call site (train/train.py:78: renderer.bind_parallel(net, args.gpu_id) =
+    DataParallel(dim=1), loss.backward() through it): with two devices listed -- here twice the one GPU, two replicas -- every
+    device runs the training forward and backward of its ray range and autograd sums the replicas' gradients into the
+    master's parameters.  Against the single-device call on the same batch: rendered outputs bit-equal, 60 gradients within
+    2e-6 of each tensor's max; then an optimizer step, and the next call (replicas re-synchronised to the stepped weights)
+    agrees again to what the slightly different weights allow."""
+    SB, ns, H, W, kc, kf, kfd, n = 2, 2, 32, 32, 16, 8, 4, 128
+    rs = np.random.RandomState(41)
+    lat = torch.from_numpy(np.concatenate([synth.latent(1810 + i, ns, 512, H // 2, W // 2) for i in range(SB)]))
+    poses = torch.from_numpy(np.stack([synth.scene_cameras(ns, radius=1.3 + 0.1 * i)[0] for i in range(SB)]))
+    rays = torch.stack([orc.gen_rays(synth.pose_spherical(100.0 + 25 * i, -20.0, 1.3)[None], W, H, 29.0, 0.3, 1.8)[0]
+                        .reshape(-1, 8)[torch.from_numpy(rs.choice(H * W, n, replace=False))] for i in range(SB)]).to(DEV)
+    gt = torch.from_numpy(rs.uniform(0, 1, size=(SB, n, 3)).astype(np.float32)).to(DEV)
+    draws = [dict(u_coarse=rs.rand(SB * n, kc).astype(np.float32), u_fine=rs.rand(SB * n, kf - kfd).astype(np.float32),
+                  u_fine2=rs.rand(SB * n, kf - kfd).astype(np.float32), g_depth=rs.randn(SB * n, kfd).astype(np.float32)) for _ in range(2)]
+
+    def run(gpus):
+        net = make_model(pconf.default_mv()["model"], stop_encoder_grad=True)
+        load_mlp(net.mlp_coarse, 1801, 512, 4)
+        load_mlp(net.mlp_fine, 1802, 512, 4)
+        net = net.to(DEV).train()
+        ren = NeRFRenderer(n_coarse=kc, n_fine=kf, n_fine_depth=kfd, white_bkgd=True).train()
+        par = ren.bind_parallel(net, gpus).train()
+        opt = torch.optim.SGD([p for p in net.parameters() if p.requires_grad], lr=0.2)
+        hist = []
+        for it in range(2):
+            net.encode(torch.zeros(SB, ns, 3, H, W), poses, torch.tensor(29.0), latent=lat)
+            ren.draws = draws[it]
+            out = par(rays, want_weights=True)
+            loss = render_loss(out, gt, True)
+            opt.zero_grad()
+            loss.backward()
+            torch.cuda.synchronize()
+            hist.append(({q + "." + k: v.detach().clone() for q in ("coarse", "fine") for k, v in out[q].items()},
+                         {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}))
+            opt.step()
+        return hist
+
+    one, two = run(None), run([0, 0])
+    for it in range(2):
+        # step 0: the same weights on both sides -- bit-equal outputs, gradients equal up to the order of two partial sums;
+        # step 1: the weights themselves differ by that much after the update
+        for k in one[it][0]:
+            if it == 0:
+                assert torch.equal(one[it][0][k], two[it][0][k]), (it, k)
+            else:
+                assert maxabs(one[it][0][k], two[it][0][k]) < 1e-5, (it, k)
+        assert len(two[it][1]) == len(one[it][1]) >= 60
+        for k, g1 in one[it][1].items():
+            scale = float(g1.abs().max())
+            # (step 1, unfiltered rays: a relu unit within ~1e-7 of zero may be masked differently by the two weight sets)
+            assert float((two[it][1][k] - g1).abs().max()) <= (2e-6 if it == 0 else 1e-3) * max(scale, 1e-20), (it, k)
+
+
 @pytest.mark.f16x2_forward
 def test_optimizer_steps_track_the_oracle():
     """Four optimizer steps of the reference's training loop (PixelNerfTrainer.py:133-156) on a super-batch of two objects: HIP
