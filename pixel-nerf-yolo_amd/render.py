@@ -54,11 +54,11 @@ class _MultiDeviceRenderWrapper(torch.nn.Module):
         without waiting, and gathers the tiles on ``gpus[0]`` with peer copies.
     Results: a ray renders to the same bits whatever range it is in (slice invariance), so with explicit draws
     the assembled output equals the single-device call bit for bit; with Philox draws each range has its own seed.
-    Training calls (grad mode, trainable MLP parameters, frozen encoder -- ``train.py --freeze_enc``) split the same way
-    (_train_split): every device runs the training forward and backward of its ray range on its replica, the replica's
-    parameters enter the graph as device copies of the master's (``p.to(device)``: autograd carries each device's gradients back
-    and sums them into the master's ``.grad``, as DataParallel's replicate / gather do), and the replicas pick the stepped
-    weights up at the next call.  With a trainable encoder (a latent that takes a gradient) the call runs on ``gpus[0]`` alone.
+    Training calls (grad mode) split the same way (_train_split): every device runs the training forward and backward of its ray
+    range on its replica, the replica's parameters enter the graph as device copies of the master's (``p.to(device)``: autograd
+    carries each device's gradients back and sums them into the master's ``.grad``, as DataParallel's replicate / gather do), and
+    the replicas pick the stepped weights up at the next call.  A latent that takes a gradient (trainable encoder: the trunk runs
+    once, on the master) is a leaf of every device's graph in the same way: each device returns its share of d loss / d latent.
     dist.py (one process per GPU, one gradient all-reduce) stays the recommended multi-GPU path: no Python serialisation of
     the per-device launches."""
 
@@ -114,15 +114,9 @@ class _MultiDeviceRenderWrapper(torch.nn.Module):
         training = torch.is_grad_enabled() and net.training and (net.trainable_mlp_parameters() or net.differentiable_latent() is not None)
         B = rays.shape[1]
         n_dev = len(self.gpus)
-        if training and B >= 64 * n_dev and net.differentiable_latent() is None and net.trainable_mlp_parameters():
+        if training and B >= 64 * n_dev:
             outputs = self._train_split(rays, want_weights)
         elif training or B < 64 * n_dev:
-            if training and B >= 64 * n_dev and not self._warned:
-                import warnings
-                warnings.warn("bind_parallel(net, gpus=%s): training calls with a trainable encoder run on cuda:%d alone "
-                              "(data-parallel training of the whole model is one process per GPU here: "
-                              "pixel_nerf_yolo_amd.dist)" % (self.gpus, self.gpus[0]))
-                self._warned = True
             outputs = ren(net, rays, want_weights=want_weights)
         else:
             outputs = self._render_split(rays, want_weights)
@@ -141,6 +135,9 @@ class _MultiDeviceRenderWrapper(torch.nn.Module):
         per = -(-per // 64) * 64
         bounds = [(min(B, i * per), min(B, (i + 1) * per)) for i in range(n_dev)]
         named = net.trainable_mlp_parameters()
+        lat_src = net.differentiable_latent()
+        if lat_src is None:
+            net.check_differentiable()
         kf = int(ren.n_fine) if (ren.using_fine and ren.n_fine > 0) else 0
         draws, calls = ren.draws, ren._calls
         ren.draws = None
@@ -158,7 +155,10 @@ class _MultiDeviceRenderWrapper(torch.nn.Module):
                     if draws is not None:
                         ren.draws = {k: torch.as_tensor(v).reshape(SB, B, -1)[:, lo:hi].reshape(SB * (hi - lo), -1) for k, v in draws.items()}
                     leaves = [p if p.device == dev else p.to(dev) for _, p in named]
-                    outs = _RenderFunction.apply(ren, r, rays[:, lo:hi].to(dev), kf > 0, len(leaves), *leaves)
+                    n_params = len(leaves)
+                    if lat_src is not None:   # a latent that takes a gradient (trainable encoder): each device returns its share
+                        leaves.append(lat_src if lat_src.device == dev else lat_src.to(dev))
+                    outs = _RenderFunction.apply(ren, r, rays[:, lo:hi].to(dev), kf > 0, n_params, *leaves)
                 parts.append([o.to(dev0) for o in outs])
         finally:
             ren._calls, ren.draws = calls + n_dev, None

@@ -652,7 +652,8 @@ def test_grouped_scene_through_the_abi(monkeypatch):
         plib.check(L_.pny_scene_set_groups(g, SB))
 
 
-def test_bind_parallel_training_on_several_devices():
+@pytest.mark.parametrize("lat_grad", [False, True])
+def test_bind_parallel_training_on_several_devices(lat_grad):
     """The reference's multi-GPU training call site (train/train.py:78: renderer.bind_parallel(net, args.gpu_id) =
     DataParallel(dim=1), loss.backward() through it): with two devices listed -- here twice the one GPU, two replicas -- every
     device runs the training forward and backward of its ray range and autograd sums the replicas' gradients into the
@@ -679,15 +680,18 @@ def test_bind_parallel_training_on_several_devices():
         opt = torch.optim.SGD([p for p in net.parameters() if p.requires_grad], lr=0.2)
         hist = []
         for it in range(2):
-            net.encode(torch.zeros(SB, ns, 3, H, W), poses, torch.tensor(29.0), latent=lat)
+            lt = lat.clone().to(DEV).requires_grad_(lat_grad)      # (a latent that takes a gradient: what a trainable encoder hands over)
+            net.encode(torch.zeros(SB, ns, 3, H, W), poses, torch.tensor(29.0), latent=lt)
             ren.draws = draws[it]
             out = par(rays, want_weights=True)
             loss = render_loss(out, gt, True)
             opt.zero_grad()
             loss.backward()
             torch.cuda.synchronize()
-            hist.append(({q + "." + k: v.detach().clone() for q in ("coarse", "fine") for k, v in out[q].items()},
-                         {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}))
+            grads = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+            if lat_grad:
+                grads["latent"] = lt.grad.clone()
+            hist.append(({q + "." + k: v.detach().clone() for q in ("coarse", "fine") for k, v in out[q].items()}, grads))
             opt.step()
         return hist
 
