@@ -233,12 +233,36 @@ class _MultiDeviceYoloWrapper(_MultiDeviceRenderWrapper):
         training = torch.is_grad_enabled() and net.training and (net.trainable_mlp_parameters() or net.differentiable_latent() is not None)
         flat = rays.reshape(-1, 8)
         N, n_dev = flat.shape[0], len(self.gpus)
-        if training or N < 64 * n_dev:
+        if N < 64 * n_dev:
             ren.net = net
             return ren(rays)
         per = -(-(-(-N // n_dev)) // 64) * 64
         bounds = [(min(N, i * per), min(N, (i + 1) * per)) for i in range(n_dev)]
         draws, calls = ren.draws, ren._calls
+        if training:   # as _MultiDeviceRenderWrapper._train_split: per-device graphs whose leaves are device copies of the master's
+            named, lat_src = net.trainable_mlp_parameters(), net.differentiable_latent()
+            if lat_src is None:
+                net.check_differentiable()
+            dev0 = torch.device("cuda", self.gpus[0])
+            parts = []
+            try:
+                for i, (lo, hi) in enumerate(bounds):
+                    if hi <= lo:
+                        continue
+                    r = self._replica(i)
+                    r.train()
+                    dev = torch.device("cuda", self.gpus[i])
+                    with torch.cuda.device(dev):
+                        ren.net, ren._calls = r, calls + i
+                        ren.draws = None if draws is None else {"u_coarse": torch.as_tensor(draws["u_coarse"]).reshape(N, -1)[lo:hi]}
+                        leaves = [p if p.device == dev else p.to(dev) for _, p in named]
+                        n_params = len(leaves)
+                        if lat_src is not None:
+                            leaves.append(lat_src if lat_src.device == dev else lat_src.to(dev))
+                        parts.append(_YoloRenderFunction.apply(ren, flat[lo:hi].to(dev), n_params, *leaves).to(dev0))
+            finally:
+                ren.net, ren._calls, ren.draws = net, calls + n_dev, None
+            return torch.cat(parts, dim=0)
         outs = []
         try:
             for i, (lo, hi) in enumerate(bounds):
@@ -717,12 +741,12 @@ class _YoloRenderFunction(torch.autograd.Function):
         lat = params[n_params] if len(params) > n_params else None
         ctx.lat_meta = None if lat is None else (tuple(lat.shape), lat.device, lat.dtype)
         out, saved = renderer._render(rays, keep_raw=True)
-        ctx.renderer, ctx.saved = renderer, saved
+        ctx.renderer, ctx.saved, ctx.net = renderer, saved, renderer.net   # (the net of THIS call: a per-device replica under bind_parallel)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        net, sv = ctx.renderer.net, ctx.saved
+        net, sv = ctx.net, ctx.saved
         L = _lib.load()
         dev = net._device()
         grads = net.bind_mlp_grads()

@@ -815,6 +815,38 @@ def test_yolo_render_backward_vs_oracle():
     compare_param_grads(net, sc, which=("mlp_coarse",))
 
 
+def test_yolo_bind_parallel_training_on_several_devices():
+    """YoloRenderer.bind_parallel(net, gpus) in training mode (YoloTrainer.py:113,160-186 with several devices; reference
+    yolo.py:116-121 = DataParallel(dim=1)): two replicas on the one GPU, each with its half of the rays; output bit-equal to the
+    single-device call, mlp_coarse gradients and the latent gradient within 2e-6 of each tensor's max."""
+    from pixel_nerf_yolo_amd.render import YoloRenderer
+    n, K = 192, 32
+    _, tgt_c2w = synth.scene_cameras(2, radius=4.0, phi=-25.0)
+    flipyz = np.diag([1.0, -1.0, -1.0, 1.0]).astype(np.float32)
+    tgt_w2c = np.linalg.inv(tgt_c2w @ flipyz).astype(np.float32)
+    rays = orc.gen_rays_yolo(tgt_w2c[None], 16, 12, [5.0, 5.5], [8.0, 6.0], 1.0, 6.0)[0].reshape(-1, 8)[:n]
+    rs = np.random.RandomState(23)
+    u = rs.rand(n, K).astype(np.float32)
+    G = torch.from_numpy(rs.standard_normal((n, 3, 7)).astype(np.float32)).to(DEV)
+    res = {}
+    for gpus in (None, [0, 0]):
+        net, _ = scene_pair(2, 64, 64, 1792, 21, 5, 3, 1500, yolo=True, lat_hw=(8, 8), lat_grad=True)
+        ren = YoloRenderer(K, 128, 1, 3)
+        par = ren.bind_parallel(net, gpus)
+        ren.draws = dict(u_coarse=u)
+        out = par(rays[None].to(DEV))
+        assert out.requires_grad and out.shape == (n, 3, 7)
+        (out * G).sum().backward()
+        torch.cuda.synchronize()
+        grads = {k: p.grad.clone() for k, p in net.mlp_coarse.named_parameters()}
+        grads["latent"] = net.test_latent.grad.clone()
+        res["one" if gpus is None else "two"] = (out.detach().clone(), grads)
+    assert torch.equal(res["one"][0], res["two"][0])
+    for k, g1 in res["one"][1].items():
+        scale = float(g1.abs().max())
+        assert scale > 0 and float((res["two"][1][k] - g1).abs().max()) <= 2e-6 * scale, k
+
+
 def test_latent_gradient_yolo_render_and_query():
     """The same gradient through the other two autograd entry points: YoloRenderer (the fork's training path: the latent comes
     from the YOLOv7 backbone, L = 1792, culled taps contribute nothing) and PixelNeRFNet.forward (query)."""
