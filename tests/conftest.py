@@ -17,6 +17,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "f16x2_forward: backward test that keeps the default (f16x2) training forward")
+    config.addinivalue_line("markers", "one_backward_leg: the test does not depend on the backward's matrix arithmetic (default leg only)")
 
 
 def pytest_collection_modifyitems(config, items):
@@ -24,7 +25,14 @@ def pytest_collection_modifyitems(config, items):
     module fixture's fp32-backward leg is not a test (it used to be collected and skipped)."""
     keep, drop = [], []
     for it in items:
-        (drop if ("default_arithmetic" in it.nodeid and "[dw_f32" in it.nodeid) else keep).append(it)
+        f32_leg = "[dw_f32" in it.nodeid
+        na = f32_leg and "default_arithmetic" in it.nodeid
+        # tests whose subject does not depend on the backward's matrix arithmetic (no MLP backward in them, or HIP against HIP
+        # on the same arithmetic) run under the default leg only: marker one_backward_leg
+        na = na or (f32_leg and it.get_closest_marker("one_backward_leg") is not None)
+        # the per-object launch forms of the super-batch test: both legs for the default form ("group"), one for the others
+        na = na or (f32_leg and "test_render_backward_super_batch" in it.nodeid and not it.nodeid.endswith("-group]"))
+        (drop if na else keep).append(it)
     if drop:
         config.hook.pytest_deselected(items=drop)
         items[:] = keep

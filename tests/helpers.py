@@ -126,8 +126,39 @@ def check_against_nerf_golden(g, out, dbg, tol, max_flips=2):
 
 
 # --------------------------------------------------------------------------- relu-safe points / rays (gradient comparisons)
+# The backward tests run under two backward arithmetics (fixture legs `dw_f32` / `dw_f16x2`) on the SAME seeded inputs: the
+# selection of unambiguous points / rays -- an oracle pass over all candidates on the CPU -- is the same in both legs and is
+# remembered per (test, parameters without the leg, call number).
+_SELECT_MEMO = {}
+_SELECT_CALLS = {}
+
+
+def _select_key(kind, extra):
+    import os
+    import re
+    cur = os.environ.get("PYTEST_CURRENT_TEST", "")
+    leg = re.search(r"\[(dw_f32|dw_f16x2)-?", cur)
+    base = re.sub(r"(dw_f32|dw_f16x2)-?", "", cur.split(" ")[0])
+    if not leg:
+        return None
+    cnt_key = (cur.split(" ")[0], kind)
+    _SELECT_CALLS[cnt_key] = _SELECT_CALLS.get(cnt_key, 0) + 1
+    return (base, kind, _SELECT_CALLS[cnt_key], extra)
+
+
 def clean_points(sc, xyz, vd, n, ambig=1e-5):
     """First n of the candidate points whose relu inputs (both MLPs, traced through the oracle) all satisfy |h| >= ambig."""
+    import pnyolo_oracle as orc
+    key = _select_key("points", (int(len(xyz)), int(n), float(ambig), float(np.asarray(xyz, dtype=np.float64).sum())))
+    if key is not None and key in _SELECT_MEMO:
+        return _SELECT_MEMO[key].copy()
+    out = _clean_points(sc, xyz, vd, n, ambig)
+    if key is not None:
+        _SELECT_MEMO[key] = out.copy()
+    return out
+
+
+def _clean_points(sc, xyz, vd, n, ambig):
     import pnyolo_oracle as orc
     orc.RELU_TRACE = []
     with torch.no_grad():
@@ -145,6 +176,17 @@ def clean_rays(sc, rays, kc, kf, kfd, draws, n, chunk=160, ambig=1e-5, **kw):
     """First n of the candidate rays all of whose samples (coarse and fine pass) are unambiguous.  Rays are independent in the
     oracle, so the candidates are traced chunk by chunk and the search stops once n are found (the oracle on the CPU is what
     these tests spend their time in)."""
+    key = _select_key("rays", (int(rays.shape[0]), kc, kf, kfd, int(n), float(ambig), float(np.asarray(rays, dtype=np.float64).sum()),
+                               float(np.asarray(draws["u_coarse"], dtype=np.float64).sum())))
+    if key is not None and key in _SELECT_MEMO:
+        return _SELECT_MEMO[key].copy()
+    out = _clean_rays(sc, rays, kc, kf, kfd, draws, n, chunk, ambig, **kw)
+    if key is not None:
+        _SELECT_MEMO[key] = out.copy()
+    return out
+
+
+def _clean_rays(sc, rays, kc, kf, kfd, draws, n, chunk=160, ambig=1e-5, **kw):
     import pnyolo_oracle as orc
     found, N = [], rays.shape[0]
     for lo in range(0, N, chunk):

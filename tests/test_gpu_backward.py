@@ -49,6 +49,7 @@ def grad_check(name, got, ref, rtol=RTOL):
 
 
 # --------------------------------------------------------------------------- composite
+@pytest.mark.one_backward_leg
 @pytest.mark.parametrize("K,white", [(16, True), (64, False), (96, True), (192, True)])
 def test_composite_backward_vs_autograd(K, white):
     rs = np.random.RandomState(K)
@@ -306,6 +307,7 @@ def test_latent_gradient_vs_oracle_autograd(L, frozen_mlp):
         assert all(p.grad is None for p in net.mlp_coarse.parameters())
 
 
+@pytest.mark.one_backward_leg
 def test_latent_gradient_run_to_run_spread():
     """The latent gradient is the one output summed with float atomics (csrc/latent_grad.hip: the order in which tiles reach a
     latent pixel is not fixed).  The bound that is documented and held here: two backward passes over the
@@ -610,6 +612,7 @@ def test_grouped_super_batch_equals_per_object(lat_grad, monkeypatch):
         assert torch.equal(out_r[k], out_r0[k]), k
 
 
+@pytest.mark.one_backward_leg
 def test_grouped_scene_through_the_abi(monkeypatch):
     """pny_scene_set_groups at the C ABI, without the Python render path: pny_query on a grouped scene (points in n_objs equal
     shares, whole 64-point tiles each) returns what the per-object scenes return, bit for bit, with a 1792-channel latent
@@ -652,6 +655,7 @@ def test_grouped_scene_through_the_abi(monkeypatch):
         plib.check(L_.pny_scene_set_groups(g, SB))
 
 
+@pytest.mark.one_backward_leg
 @pytest.mark.parametrize("lat_grad", [False, True])
 def test_bind_parallel_training_on_several_devices(lat_grad):
     """The reference's multi-GPU training call site (train/train.py:78: renderer.bind_parallel(net, args.gpu_id) =
@@ -815,6 +819,7 @@ def test_yolo_render_backward_vs_oracle():
     compare_param_grads(net, sc, which=("mlp_coarse",))
 
 
+@pytest.mark.one_backward_leg
 def test_yolo_bind_parallel_training_on_several_devices():
     """YoloRenderer.bind_parallel(net, gpus) in training mode (YoloTrainer.py:113,160-186 with several devices; reference
     yolo.py:116-121 = DataParallel(dim=1)): two replicas on the one GPU, each with its half of the rays; output bit-equal to the
