@@ -40,6 +40,26 @@ def test_abi_exports_every_declared_symbol(built_lib):
     assert built_lib.pny_version() == plib.ABI_VERSION == 11
 
 
+def test_header_is_plain_c_and_links(built_lib, tmp_path):
+    """include/pnyolo.h is the boundary a C / cgo / JNI host binds: it compiles as strict C99 (-pedantic, no warnings) without
+    any HIP or torch header, and a C program linked against the shared library gets the ABI version it was compiled for."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not installed")
+    src = tmp_path / "abi.c"
+    src.write_text('#include "pnyolo.h"\n#include <stdio.h>\n'
+                   "int main(void) { pny_render_opts o; pny_render_out r; pny_model_desc d; (void)o; (void)r; (void)d;\n"
+                   '  printf("%d\\n", pny_version()); return pny_version() == PNY_ABI_VERSION ? 0 : 1; }\n')
+    exe = tmp_path / "abi"
+    libdir = os.path.dirname(plib.LIB_PATH)
+    cc = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                         "-L", libdir, "-lpnyolo", "-Wl,-rpath," + libdir], capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert run.returncode == 0 and run.stdout.strip() == str(plib.ABI_VERSION), (run.returncode, run.stdout, run.stderr)
+
+
 def test_no_wide_store_with_sgpr_soffset_is_followed_by_a_write_of_its_data(built_lib):
     """The write-data hazard of profiles/r03_anomalies.md (B), checked statically on the built code objects: a > 64-bit buffer
     store with an SGPR soffset directly followed by an instruction that writes its data registers is a form the compiler does
