@@ -370,3 +370,75 @@ def test_eval_from_a_dataset_directory(tmp_path):
                      draws["g_depth"][sub])
     diff = (rgb[0].cpu()[sub] - ref["fine"]["rgb"]).abs().max(dim=1)[0]
     assert int((diff > TOL).sum()) <= 2 and float(diff.median()) < 1e-5
+
+
+@pytest.mark.parametrize("d_lat", [512, 1792])
+def test_plain_c_host_through_the_abi(d_lat, tmp_path):
+    """The boundary from a host that is not Python: examples/abi_host.c (C99, HIP's C API for its own device memory, default
+    stream, no torch in the process) is compiled with gcc against include/pnyolo.h + libpnyolo.so, fed one file with the
+    weights by state_dict name, a latent, cameras, rays and the renderer's draws, and its coarse / fine rgb and depth are
+    compared with the Python mirror's on the same inputs: bit for bit."""
+    import shutil
+    import struct
+    import subprocess
+    from pixel_nerf_yolo_amd import lib as plib
+    if shutil.which("gcc") is None or not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
+        pytest.skip("gcc or the HIP headers are not installed")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe, libdir = str(tmp_path / "abi_host"), os.path.dirname(plib.LIB_PATH)
+    cc = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(root, "include"),
+                         "-I", "/opt/rocm/include", os.path.join(root, "examples", "abi_host.c"), "-o", exe, "-L", libdir, "-lpnyolo",
+                         "-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    ns, H, W, hw, n, kc, kf, kfd = 3, 64, 64, 16, 200, 32, 16, 8
+    rs = np.random.RandomState(d_lat)
+    sd = {}
+    sd.update({"mlp_coarse." + k: v for k, v in synth.mlp_state(2101, d_latent=d_lat).items()})
+    sd.update({"mlp_fine." + k: v for k, v in synth.mlp_state(2102, d_latent=d_lat).items()})
+    lat = synth.latent(2103, ns, d_lat, hw, hw)
+    poses, tgt = synth.scene_cameras(ns)
+    focal, cc_ = np.array([0.9 * W, 0.9 * W], np.float32), np.array([W * 0.5, H * 0.5], np.float32)
+    rays = gen_rays(torch.from_numpy(tgt)[None], W, H, torch.tensor(0.9 * W), 0.8, 1.8).reshape(-1, 8)[torch.from_numpy(rs.choice(H * W, n, replace=False))]
+    dr = dict(u_coarse=rs.rand(n, kc).astype(np.float32), u_fine=rs.rand(n, kf - kfd).astype(np.float32),
+              u_fine2=rs.rand(n, kf - kfd).astype(np.float32), g_depth=rs.randn(n, kfd).astype(np.float32))
+    # ---- the Python mirror
+    conf = pconf.default_mv()
+    if d_lat != 512:
+        conf.d["model"]["encoder"]["backbone"] = "custom"
+    net = make_model(conf["model"]).eval()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    net = net.to(DEV)
+    net.encode(torch.zeros(1, ns, 3, H, W), torch.from_numpy(poses)[None], torch.tensor(0.9 * W), c=torch.from_numpy(cc_)[None],
+               latent=torch.from_numpy(lat))
+    ren = NeRFRenderer(n_coarse=kc, n_fine=kf, n_fine_depth=kfd, depth_std=0.01, white_bkgd=True).eval()
+    ren.draws = dr
+    with torch.no_grad():
+        out = ren(net, rays[None].to(DEV))
+    torch.cuda.synchronize()
+    # ---- the same through the C program
+    inp, outp = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(inp, "wb") as f:
+        f.write(struct.pack("<i", 0x504E5931))
+        f.write(struct.pack("<6if4i", d_lat, 512, 4, 5, 3, 6, 1.5, 0, 1, 0, 1))
+        f.write(struct.pack("<i", len(sd)))
+        for k, v in sd.items():
+            kb = k.encode()
+            f.write(struct.pack("<i", len(kb)) + kb + struct.pack("<i", v.ndim) + struct.pack("<%dq" % v.ndim, *v.shape))
+            f.write(np.ascontiguousarray(v, np.float32).tobytes())
+        f.write(struct.pack("<6i", ns, d_lat, hw, hw, W, H))
+        f.write(np.ascontiguousarray(lat, np.float32).tobytes())
+        f.write(np.ascontiguousarray(poses, np.float32).tobytes())
+        f.write(focal.tobytes() + cc_.tobytes())
+        f.write(struct.pack("<5if", n, kc, kf, kfd, 1, 0.01))
+        f.write(np.ascontiguousarray(rays.cpu().numpy(), np.float32).tobytes())
+        for k in ("u_coarse", "u_fine", "u_fine2", "g_depth"):
+            f.write(dr[k].tobytes())
+    env = dict(os.environ)
+    run = subprocess.run([exe, inp, outp], capture_output=True, text=True, env=env)
+    assert run.returncode == 0, (run.returncode, run.stdout, run.stderr)
+    got = np.fromfile(outp, np.float32)
+    assert got.size == 8 * n
+    parts = dict(rgb_c=got[:3 * n].reshape(n, 3), depth_c=got[3 * n:4 * n], rgb_f=got[4 * n:7 * n].reshape(n, 3), depth_f=got[7 * n:])
+    ref = dict(rgb_c=out["coarse"]["rgb"][0], depth_c=out["coarse"]["depth"][0], rgb_f=out["fine"]["rgb"][0], depth_f=out["fine"]["depth"][0])
+    for k in parts:
+        assert np.array_equal(parts[k], ref[k].cpu().numpy()), (k, float(np.abs(parts[k] - ref[k].cpu().numpy()).max()))
