@@ -577,12 +577,15 @@ class PixelNeRFNet(nn.Module):
         return out
 
     def check_differentiable(self):
-        """The backward pass covers the MLPs; the encoder must be frozen (reference: --freeze_enc / stop_encoder_grad,
-        train/train.py:70-73, models.py:33-35)."""
+        """Called by a training render / query when the latent of the last encode() carries no graph.  Fine with a frozen
+        encoder (reference: --freeze_enc / stop_encoder_grad, train/train.py:70-73, models.py:33-35); with a trainable one the
+        gradient would silently stop at the latent, so this is an error: encode() must run in train() mode with grad enabled
+        (the library's training trunk, model._TrunkFunction) or be given a latent that requires grad."""
         if not self.stop_encoder_grad and any(p.requires_grad for p in self.encoder.parameters()):
             raise NotImplementedError(
-                "libpnyolo differentiates the MLPs only: freeze the encoder (make_model(conf, stop_encoder_grad=True) "
-                "or requires_grad_(False) on net.encoder, as the reference's --freeze_enc does)")
+                "the encoder has trainable parameters but the latent of the last encode() carries no graph (encode() ran in "
+                "eval() mode or under no_grad): call net.encode(...) in train() mode with grad enabled, or freeze the encoder "
+                "(make_model(conf, stop_encoder_grad=True) / requires_grad_(False) on net.encoder, the reference's --freeze_enc)")
 
     def differentiable_latent(self):
         """The latent tensor of the last encode(latent=...) if it requires grad and autograd is recording in train() mode

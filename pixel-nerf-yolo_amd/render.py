@@ -456,8 +456,9 @@ class NeRFRenderer(torch.nn.Module):
 
         Under autograd (grad mode on, ``model.train()`` and MLP parameters that require grad) the call goes through ``_RenderFunction``:
         same forward kernels, and ``loss.backward()`` fills ``.grad`` of the MLP parameters through
-        pny_render_backward (include/pnyolo.h).  The encoder is not differentiated: it must be frozen
-        (``stop_encoder_grad`` / ``--freeze_enc`` of the reference, train/train.py:70-73)."""
+        pny_render_backward (include/pnyolo.h).  With an unfrozen encoder (the reference's default, train/train.py:66-73) the
+        backward also returns d loss / d latent to the latent of the last ``encode()`` -- the library's training trunk
+        (model._TrunkFunction) or a latent supplied by the caller."""
         if self.sched is not None and self.last_sched.item() > 0:
             self.n_coarse = self.sched[1][self.last_sched.item() - 1]
             self.n_fine = self.sched[2][self.last_sched.item() - 1]
