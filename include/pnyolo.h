@@ -87,7 +87,8 @@ int pny_model_finalize(pny_model* m);
  * lives on the device (fp32, contiguous, its state_dict shape; borrowed until rebound); after the parameters changed
  * in place (optimizer.step()), pny_model_refresh re-creates every packed operand of both MLPs from those tensors with
  * one kernel launch on `stream` (no host round trip, asynchronous; ordered behind the scenes' earlier calls).
- * pny_model_finalize must have run once (it fixes the layout); encoder weights are not refreshed (frozen encoder). */
+ * pny_model_finalize must have run once (it fixes the layout).  The inference trunk's folded weights are not refreshed (they
+ * follow pny_model_load_weights + finalize); the training trunk (pny_trunk_train_forward) reads its bound parameters directly. */
 int pny_model_bind_param(pny_model* m, const char* name, const float* param_dev);
 int pny_model_refresh(pny_model* m, pny_stream stream);
 /* `net.mlp_fine = None` (reference eval/eval.py:140): with enable=0 the fine pass of pny_render and
@@ -328,8 +329,8 @@ int pny_scene_enable_timing(pny_scene* s, int enable);
  * the dX chain and the weight-gradient GEMMs run over the stash.
  * The fine pass's depth samples depend on the coarse depth in the reference (nerf.py:156-167: no detach): that path
  * (gradient w.r.t. sample positions through the positional code, the projection and the bilinear latent lookup) is
- * included.  The latent is differentiated through pny_scene_bind_latent_grad (below); not differentiated: the encoder's
- * convolutions (the gradient is handed to whoever produced the latent), the rays, the cameras. */
+ * included.  The latent is differentiated through pny_scene_bind_latent_grad (below), and the ResNet-34 trunk from there by
+ * pny_trunk_train_backward; not differentiated: the rays, the cameras. */
 
 /* Gradient target of the state_dict entry `name` ("mlp_coarse.blocks.2.fc_1.weight", ...): a device buffer of the
  * parameter's shape (fp32, contiguous) that the backward calls write / add into.  NULL unbinds.  Borrowed until
@@ -340,8 +341,8 @@ int pny_model_bind_grad(pny_model* m, const char* name, float* grad_dev);
  * (src/model/resnetfc.py:176-182), i.e. what reaches `encoder.latent` in the reference when the encoder trains:
  * grad_dev is a caller-owned, caller-zeroed fp32 buffer of the latent's shape in the library's layout (ns, Hl, Wl, L)
  * (channel-last); every backward call on the scene ADDS into it (float atomics: reproducible to fp32 rounding, not bit for
- * bit).  NULL unbinds.  d_latent must be a multiple of 256.  The encoder itself is not differentiated here: the gradient is
- * handed to whatever produced the latent (pny_scene_set_latent). */
+ * bit).  NULL unbinds.  d_latent must be a multiple of 256.  The gradient is handed to whatever produced the latent
+ * (pny_scene_set_latent): pny_trunk_train_backward for the library's trunk, the caller's own backbone otherwise. */
 int pny_scene_bind_latent_grad(pny_scene* s, float* grad_dev);
 
 /* Backward of pny_query: d_out_dev (n, d_out) = dL/d(out).  accumulate = 0 overwrites the bound gradients of the

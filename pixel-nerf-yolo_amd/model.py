@@ -162,10 +162,11 @@ class SpatialEncoder(nn.Module):
         self.index_interp, self.index_padding, self.upsample_interp = index_interp, index_padding, upsample_interp
 
     def forward_torch(self, x):
-        """The trunk as a differentiable torch graph (reference encoder.py:110-173, resnet34 branch): used by
-        ``PixelNeRFNet.encode`` when the encoder TRAINS -- the library's own trunk (csrc/encoder.hip) is forward only, so the
-        convolutions and batch norms (train-mode statistics when ``self.training``) then run through ATen and autograd,
-        and the renderer's backward hands d loss / d latent back to this graph (pny_scene_bind_latent_grad)."""
+        """The trunk as a differentiable torch graph (reference encoder.py:110-173, resnet34 branch): the ATen alternative to the
+        library's training trunk (csrc/encoder_train.hip, model._TrunkFunction), taken by ``PixelNeRFNet.encode`` with
+        PNYOLO_TRUNK=torch or when the library cannot read the trunk's parameters in place.  Convolutions and batch norms
+        (train-mode statistics when ``self.training``) run through ATen and autograd, and the renderer's backward hands
+        d loss / d latent back to this graph (pny_scene_bind_latent_grad)."""
         import torch.nn.functional as F
         if self.use_custom_resnet:
             raise RuntimeError("backbone=custom has no trunk here: supply the latent")
@@ -345,8 +346,8 @@ class PixelNeRFNet(nn.Module):
             old = self._synced_key
             # Only MLP tensors changed IN PLACE (same storage, new version: an optimizer step) -> device-side refresh:
             # one kernel launch re-creates the packed operands from the live parameters (pny_model_refresh).
-            # Encoder tensors stepped in place (encoder training: the trunk then runs in torch, encode()) only mark the native
-            # trunk's copy stale; it is re-uploaded when the native trunk is next needed (_need_native_encoder).
+            # Encoder tensors stepped in place (encoder training: the training trunk reads the live parameters itself) only mark
+            # the INFERENCE trunk's folded copy stale; it is re-uploaded when that trunk is next needed (encode() outside training).
             in_place = (old is not None and self._dev_bound and len(old) == len(key) and
                         all(a[:2] == b[:2] and (a[2] == b[2] or a[0].startswith(("mlp_", "encoder."))) for a, b in zip(old, key)))
             if in_place:
@@ -717,8 +718,9 @@ class PixelNeRFNet(nn.Module):
         if latent is None and self.encoder.use_custom_resnet:
             raise RuntimeError("backbone=custom (YOLOv7) has no kernels in this build (its source and weights are "
                                "outside the reference tree): pass the backbone output via encode(..., latent=...)")
-        # Encoder training (the reference's default: train/train.py without --freeze_enc): the trunk runs as a torch graph and
-        # its output enters like a supplied latent; the render backward returns d loss / d latent to that graph
+        # Encoder training (the reference's default: train/train.py without --freeze_enc): the trunk runs on the library's training
+        # kernels under autograd (_TrunkFunction; the ATen graph forward_torch as the alternative) and its output enters like a
+        # supplied latent; the render backward returns d loss / d latent to it
         if (latent is None and not self.encoder.use_custom_resnet and torch.is_grad_enabled() and self.training
                 and not self.stop_encoder_grad and any(p.requires_grad for p in self.encoder.parameters())):
             if self._native_trunk_training():
